@@ -1,0 +1,130 @@
+/*
+ * marex_hip.h -- C ABI of the MI355X (gfx950) hot path behind marEx-style preprocess_data().
+ *
+ * The reference (wienkers/marEx) is pure Python and has NO plugin / FFI interface: its boundary for
+ * this path is the Python call marEx.preprocess_data() (marEx/detect.py:287-313).  This header is
+ * therefore the build-defined drop-in boundary: one entry point per numerical stage
+ * of that call, each citing the reference lines it replaces.  The Python host side
+ * (marex_amd/detect.py) binds it with ctypes; INTEGRATION.md shows the stub a marEx maintainer
+ * would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error; marex_last_error(ctx) gives the text.
+ *  - no exceptions / longjmp cross the ABI; the library allocates nothing but the opaque context.
+ *  - ALL data pointers are DEVICE pointers owned by the caller (small tables included).
+ *  - work is enqueued on the context's HIP stream (marex_set_stream); marex_sync waits for it.
+ *  - field layout is the reference's C-order (time, cells): element (t, c) at [t*C + c].
+ *  - one context per (device, host thread).
+ */
+#ifndef MAREX_HIP_H
+#define MAREX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAREX_ABI_VERSION 1
+#define MAREX_NDOY 366
+
+typedef struct marex_ctx marex_ctx;
+
+/* statistics of the threshold stage, device resident (detect.py:2707-2732 warnings) */
+typedef struct marex_thr_stats {
+    uint32_t min_key;   /* order-preserving key of the smallest un-clamped threshold (0xFFFFFFFF if none) */
+    uint32_t max_key;   /* order-preserving key of the largest threshold (0 if none)                      */
+    uint32_t n_too_low; /* thresholds < lower_bound (they are clamped to it)                              */
+    uint32_t n_too_high;/* thresholds > upper_bound                                                       */
+} marex_thr_stats;
+
+/* kernel ids for marex_timing_get */
+enum {
+    MAREX_K_SYNTH = 0,
+    MAREX_K_SHIFTING = 1,     /* smoothing + rolling climatology + anomaly + binning + validation */
+    MAREX_K_THRESHOLDS = 2,   /* pooled day-of-year histogram quantile                             */
+    MAREX_K_MASK = 3,         /* anomaly >= threshold                                              */
+    MAREX_K_TRANSPOSE = 4,
+    MAREX_K_FIXED = 5,
+    MAREX_K_DETREND = 6,
+    MAREX_K_EXACT = 7,
+    MAREX_K_GLOBAL = 8,
+    MAREX_K_COUNT = 9
+};
+
+int marex_abi_version(void);
+int marex_create(int device, marex_ctx** out);
+int marex_destroy(marex_ctx* ctx);
+const char* marex_last_error(marex_ctx* ctx);
+int marex_set_stream(marex_ctx* ctx, void* hip_stream);
+int marex_sync(marex_ctx* ctx);
+
+/* per-kernel device timing with HIP events on the context's stream (used by bench.py) */
+int marex_timing_enable(marex_ctx* ctx, int on);
+int marex_timing_reset(marex_ctx* ctx);
+int marex_timing_get(marex_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
+
+/* Synthetic SST field of marex_amd/synth.py, bit-identical to the NumPy version (test/bench utility). */
+int marex_synth_sst_f32(marex_ctx* ctx, const float* mean, const float* amp, const uint8_t* hemi,
+                        const uint8_t* land, const float* seas /*[T,2]*/, const float* trend /*[T]*/,
+                        uint64_t seed, int64_t cell_base, int64_t T, int64_t C, float* x /*[T,C]*/);
+
+/*
+ * Shifting-baseline anomaly, fused with validation counting and histogram binning.
+ * Replaces: _validate_data_values (detect.py:205-279), smoothed_rolling_climatology (1691-1816),
+ * rolling_climatology (1511-1688), _compute_anomaly_shifting_baseline (1819-1850), the year trim
+ * (615-641) and the np.digitize step of _compute_histogram_quantile_2d (2622-2631).
+ *
+ *  tindex[n_cal_years*366]  timestep of (calendar-year index, dayofyear-1) or -1
+ *  out_index[T]             output row of timestep t or -1 (trimmed)
+ *  rowb_index[T]            row of timestep t in the dayofyear-sorted bin matrix or -1
+ *  first_valid_year         first calendar-year index that gets a climatology (= W)
+ *  write_clim               0: out = x - clim (anomaly); 1: out = clim (rolling_climatology API)
+ *  edges[nb+1], bins        bin table and output [T_out, C] uint16 (both may be NULL: no binning)
+ *  mask[C]                  isfinite(x[0, c])                     (may be NULL)
+ *  invalid_count[C]         number of non-finite x[t, c] over t; must be zeroed by the caller (may be NULL)
+ */
+int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
+                                const int32_t* tindex, int n_cal_years, int first_valid_year,
+                                const int32_t* out_index, const int32_t* rowb_index, int W, int S,
+                                int write_clim, const float* edges, int nb, float* out,
+                                uint16_t* bins, uint8_t* mask, int32_t* invalid_count);
+
+/*
+ * Day-of-year thresholds from pooled histograms (approximate percentile method).
+ * Replaces: the flox 2-D count + spatial pooling + per-cell _rolling_histogram_quantile +
+ * NaN-masking + clamp of _compute_histogram_quantile_2d (detect.py:2638-2732, 2465-2559).
+ *
+ *  bins[T_out, C]     uint16 bin ids, rows sorted by (dayofyear, time) (see rowb_index above)
+ *  doy_start[367]     rows doy_start[d-1]..doy_start[d]-1 hold dayofyear d
+ *  ny, nx             grid (cells = ny*nx, lon fastest); ny == 0: unstructured, no pooling (ws must be <= 1)
+ *  first_anom[C]      first kept anomaly row; NaN there => threshold NaN (detect.py:2704)
+ *  centres[nb]        float32 bin centres, centres[0] == 0
+ *  q, wd, ws          quantile in (0,1], odd day window (3..365), odd spatial window (1 = none)
+ *  lower/upper_bound  edges[3] / edges[-2]
+ *  thr_doy_major      out [366, C]   (dayofyear-major working layout used by marex_mask_ge_doy_f32)
+ *  stats              device struct, must be initialised {0xFFFFFFFF, 0, 0, 0} by the caller
+ */
+int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins, int64_t T_out, int64_t C, int ny,
+                                int nx, const int32_t* doy_start, const float* first_anom,
+                                const float* centres, int nb, double q, int wd, int ws,
+                                float lower_bound, float upper_bound, float* thr_doy_major,
+                                marex_thr_stats* stats);
+
+/*
+ * extreme[t, c] = anom[t, c] >= thr[doy(t), c]   (detect.py:2003-2004) and the count of True (833-835).
+ *  doy_rows[T_out]   output rows sorted by (dayofyear, time); doy_start as above
+ *  n_true            device counter, must be zeroed by the caller (may be NULL)
+ */
+int marex_mask_ge_doy_f32(marex_ctx* ctx, const float* anom, const float* thr_doy_major,
+                          const int32_t* doy_start, const int32_t* doy_rows, int64_t T_out, int64_t C,
+                          uint8_t* extreme, unsigned long long* n_true);
+
+/* out[c, r] = in[r, c]  (thresholds [366, C] -> the reference's (cells, dayofyear) order) */
+int marex_transpose_f32(marex_ctx* ctx, const float* in, int64_t rows, int64_t cols, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAREX_HIP_H */

@@ -1,0 +1,134 @@
+"""ctypes binding of ``libmarex_hip.so`` (C ABI declared in ``include/marex_hip.h``).
+
+The product path has no CPU fallback: if the shared library is missing or does not export the
+declared symbols, loading raises :class:`marex_amd.exceptions.DependencyError`.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from .exceptions import DependencyError, ProcessingError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmarex_hip.so")
+
+_p = C.c_void_p
+_i32 = C.c_int
+_i64 = C.c_int64
+_u64 = C.c_uint64
+_f32 = C.c_float
+_f64 = C.c_double
+
+#: name -> (restype, argtypes); must list every function declared in include/marex_hip.h
+PROTOTYPES = {
+    "marex_abi_version": (_i32, []),
+    "marex_create": (_i32, [_i32, C.POINTER(_p)]),
+    "marex_destroy": (_i32, [_p]),
+    "marex_last_error": (C.c_char_p, [_p]),
+    "marex_set_stream": (_i32, [_p, _p]),
+    "marex_sync": (_i32, [_p]),
+    "marex_timing_enable": (_i32, [_p, _i32]),
+    "marex_timing_reset": (_i32, [_p]),
+    "marex_timing_get": (_i32, [_p, _i32, C.POINTER(_f64), C.POINTER(_i64)]),
+    "marex_synth_sst_f32": (_i32, [_p, _p, _p, _p, _p, _p, _p, _u64, _i64, _i64, _i64, _p]),
+    "marex_shifting_baseline_f32": (
+        _i32,
+        [_p, _p, _i64, _i64, _p, _i32, _i32, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p],
+    ),
+    "marex_hobday_thresholds_f32": (
+        _i32,
+        [_p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i32, _f64, _i32, _i32, _f32, _f32, _p, _p],
+    ),
+    "marex_mask_ge_doy_f32": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _p, _p]),
+    "marex_transpose_f32": (_i32, [_p, _p, _i64, _i64, _p]),
+}
+
+KERNEL_IDS = {
+    "synth": 0,
+    "shifting": 1,
+    "thresholds": 2,
+    "mask": 3,
+    "transpose": 4,
+    "fixed": 5,
+    "detrend": 6,
+    "exact": 7,
+    "global": 8,
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library and bind every prototype; raises DependencyError when impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DependencyError(
+            "HIP extension libmarex_hip.so is not built",
+            details=f"expected at {LIB_PATH}",
+            suggestions=["run `python -m marex_amd.csrc.build` (needs hipcc, --offload-arch=gfx950)"],
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the machine
+        raise DependencyError("HIP extension libmarex_hip.so failed to load", details=str(exc)) from exc
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise DependencyError(f"libmarex_hip.so does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class Context:
+    """One opaque ``marex_ctx`` bound to a device; launches on the stream given to ``set_stream``."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        self.handle = _p()
+        rc = self.lib.marex_create(int(device), C.byref(self.handle))
+        if rc != 0:
+            raise ProcessingError(f"marex_create(device={device}) failed with code {rc} (no usable HIP device?)")
+        self.device = int(device)
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.marex_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            msg = self.lib.marex_last_error(self.handle)
+            raise ProcessingError(f"{what} failed (code {rc})", details=msg.decode() if msg else None)
+
+    def set_stream(self, stream_ptr: int) -> None:
+        self.check(self.lib.marex_set_stream(self.handle, _p(stream_ptr)), "marex_set_stream")
+
+    def sync(self) -> None:
+        self.check(self.lib.marex_sync(self.handle), "marex_sync")
+
+    def timing_enable(self, on: bool = True) -> None:
+        self.check(self.lib.marex_timing_enable(self.handle, int(on)), "marex_timing_enable")
+
+    def timing_reset(self) -> None:
+        self.check(self.lib.marex_timing_reset(self.handle), "marex_timing_reset")
+
+    def timing_get(self, kernel: str):
+        ms, n = _f64(0.0), _i64(0)
+        self.check(
+            self.lib.marex_timing_get(self.handle, KERNEL_IDS[kernel], C.byref(ms), C.byref(n)), "marex_timing_get"
+        )
+        return ms.value, n.value

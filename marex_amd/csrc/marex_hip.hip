@@ -1,0 +1,747 @@
+// marex_hip.hip -- hand-written gfx950 (CDNA4) kernels + C ABI for the preprocess_data hot path.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see csrc/build.py).
+// -ffp-contract=off is part of the arithmetic contract (oracle/marex_oracle.py C1-C6): every float
+// add / multiply / divide below is an individually rounded IEEE operation, never fused.
+//
+// All kernels are HBM / LDS bound streaming or counting kernels (no MFMA): wave64, 256-thread
+// workgroups, one lane per grid cell so that a wave reads 256 contiguous bytes of a (time, cell) row.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "marex_hip.h"
+
+#define NDOY MAREX_NDOY
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct TimedLaunch {
+    int kid;
+    hipEvent_t a, b;
+};
+
+struct marex_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool timing = false;
+    std::vector<TimedLaunch> pending;
+    double total_ms[MAREX_K_COUNT] = {0};
+    int64_t launches[MAREX_K_COUNT] = {0};
+};
+
+static int fail(marex_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) return fail(ctx, -2, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+struct LaunchTimer {
+    marex_ctx* ctx;
+    int kid;
+    hipEvent_t a = nullptr, b = nullptr;
+    LaunchTimer(marex_ctx* c, int k) : ctx(c), kid(k) {
+        if (ctx->timing) {
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            hipEventRecord(a, ctx->stream);
+        }
+    }
+    ~LaunchTimer() {
+        if (ctx->timing) {
+            hipEventRecord(b, ctx->stream);
+            ctx->pending.push_back({kid, a, b});
+        }
+    }
+};
+
+static void drain_timers(marex_ctx* ctx) {
+    for (auto& p : ctx->pending) {
+        float ms = 0.f;
+        hipEventSynchronize(p.b);
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ctx->total_ms[p.kid] += ms;
+            ctx->launches[p.kid] += 1;
+        }
+        hipEventDestroy(p.a);
+        hipEventDestroy(p.b);
+    }
+    ctx->pending.clear();
+}
+
+extern "C" int marex_abi_version(void) { return MAREX_ABI_VERSION; }
+
+extern "C" int marex_create(int device, marex_ctx** out) {
+    if (!out) return -1;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return -3;
+    marex_ctx* c = new marex_ctx();
+    c->device = device;
+    *out = c;
+    return 0;
+}
+
+extern "C" int marex_destroy(marex_ctx* ctx) {
+    if (!ctx) return -1;
+    drain_timers(ctx);
+    delete ctx;
+    return 0;
+}
+
+extern "C" const char* marex_last_error(marex_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int marex_set_stream(marex_ctx* ctx, void* s) {
+    if (!ctx) return -1;
+    ctx->stream = (hipStream_t)s;
+    return 0;
+}
+
+extern "C" int marex_sync(marex_ctx* ctx) {
+    if (!ctx) return -1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drain_timers(ctx);
+    return 0;
+}
+
+extern "C" int marex_timing_enable(marex_ctx* ctx, int on) {
+    if (!ctx) return -1;
+    ctx->timing = on != 0;
+    return 0;
+}
+
+extern "C" int marex_timing_reset(marex_ctx* ctx) {
+    if (!ctx) return -1;
+    drain_timers(ctx);
+    memset(ctx->total_ms, 0, sizeof ctx->total_ms);
+    memset(ctx->launches, 0, sizeof ctx->launches);
+    return 0;
+}
+
+extern "C" int marex_timing_get(marex_ctx* ctx, int kid, double* total_ms, int64_t* launches) {
+    if (!ctx || kid < 0 || kid >= MAREX_K_COUNT) return -1;
+    drain_timers(ctx);
+    if (total_ms) *total_ms = ctx->total_ms[kid];
+    if (launches) *launches = ctx->launches[kid];
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nan_f() { return __builtin_nanf(""); }
+__device__ __forceinline__ bool finite_f(float v) { return fabsf(v) <= 3.402823466e+38f; }
+
+// Workgroups are dealt round-robin over the 8 XCDs (b % 8).  Map the linear block id so that the
+// `inner` consecutive work items of one `outer` group (which re-read each other's rows) land on the
+// same XCD / L2.  Returns false for padding blocks.
+__device__ __forceinline__ bool xcd_swizzle(unsigned b, int n_outer, int n_inner, int& outer, int& inner) {
+    unsigned xcd = b & 7u;
+    unsigned k = b >> 3;
+    inner = (int)(k % (unsigned)n_inner);
+    outer = (int)((k / (unsigned)n_inner) * 8u + xcd);
+    return outer < n_outer;
+}
+static inline unsigned xcd_grid(int n_outer, int n_inner) { return (unsigned)(((n_outer + 7) / 8) * 8) * (unsigned)n_inner; }
+
+// np.digitize(v, edges) - 1 for an increasing table edges[0..nb] with edges[0] = -inf  (contract C4).
+// The guess assumes equal-width bins above edges[1]; the two correction loops make it exact for any
+// increasing table.
+__device__ __forceinline__ int digitize_bin(float v, const float* e, int nb, float inv_width) {
+    if (!(v == v)) return nb;
+    if (v >= e[nb]) return nb;
+    if (v < e[1]) return 0;
+    int k = 1 + (int)((v - e[1]) * inv_width);
+    k = k < 1 ? 1 : (k > nb - 1 ? nb - 1 : k);
+    while (k > 1 && v < e[k]) --k;
+    while (k < nb - 1 && v >= e[k + 1]) ++k;
+    return k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic field (marex_amd/synth.py)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned sum16(unsigned long long h) {
+    return (unsigned)(h & 0xFFFF) + (unsigned)((h >> 16) & 0xFFFF) + (unsigned)((h >> 32) & 0xFFFF) + (unsigned)(h >> 48);
+}
+
+__global__ void __launch_bounds__(256) k_synth(const float* __restrict__ mean, const float* __restrict__ amp,
+                                               const unsigned char* __restrict__ hemi,
+                                               const unsigned char* __restrict__ land,
+                                               const float* __restrict__ seas, const float* __restrict__ trend,
+                                               unsigned long long seed, long cell_base, long T, long C,
+                                               float z_scale, float noise_amp, int rows_per_block,
+                                               float* __restrict__ x) {
+    long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    long t0 = (long)blockIdx.y * rows_per_block;
+    long t1 = t0 + rows_per_block < T ? t0 + rows_per_block : T;
+    const float m = mean[c], a = amp[c];
+    const int hm = hemi[c];
+    const bool is_land = land[c] != 0;
+    const unsigned long long kc = seed * 0x9E3779B97F4A7C15ull + (unsigned long long)(c + cell_base) * 0x8CB92BA72F3D8DD7ull;
+    for (long t = t0; t < t1; ++t) {
+        float v;
+        if (is_land) {
+            v = nan_f();
+        } else {
+            unsigned long long key = kc + (unsigned long long)t * 0xD1B54A32D192ED03ull;
+            unsigned s = sum16(mix64(key)) + sum16(mix64(key ^ 0xA5A5A5A5A5A5A5A5ull));
+            float z = (float)(2 * (int)s - 8 * 65535) * z_scale;
+            float sa = a * seas[2 * t + hm];
+            float b = m + sa;
+            float cc = b + trend[t];
+            v = cc + noise_amp * z;
+        }
+        x[(size_t)t * C + c] = v;
+    }
+}
+
+extern "C" int marex_synth_sst_f32(marex_ctx* ctx, const float* mean, const float* amp, const uint8_t* hemi,
+                                   const uint8_t* land, const float* seas, const float* trend, uint64_t seed,
+                                   int64_t cell_base, int64_t T, int64_t C, float* x) {
+    if (!ctx) return -1;
+    if (!mean || !amp || !hemi || !land || !seas || !trend || !x || T <= 0 || C <= 0)
+        return fail(ctx, -1, "marex_synth_sst_f32: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rows = 64;
+    dim3 grid((unsigned)((C + 255) / 256), (unsigned)((T + rows - 1) / rows));
+    const float z_scale = (float)(1.0 / (2.0 * sqrt(8.0 * (65536.0 * 65536.0 - 1.0) / 12.0)));
+    {
+        LaunchTimer lt(ctx, MAREX_K_SYNTH);
+        hipLaunchKernelGGL(k_synth, grid, dim3(256), 0, ctx->stream, mean, amp, hemi, land, seas, trend,
+                           (unsigned long long)seed, (long)cell_base, (long)T, (long)C, z_scale, 0.8f, rows, x);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_A: shifting-baseline anomaly  (smoothing + rolling climatology + anomaly + bins + validation)
+//
+// Work item = (block of 256 consecutive cells, chunk of D consecutive dayofyears).  The workgroup
+// walks the calendar years in ascending order.  For one year the D dayofyears of the chunk are D
+// consecutive timesteps, so ONE load of D+S-1 rows (256 contiguous floats each) feeds the S-step
+// smoothing of all D days out of registers.  The W-year history of every (cell, dayofyear) lives in
+// an LDS ring [D][W][256] that is private per lane (no barriers in the year loop).  Each input row
+// is read by ceil((D+S-1)/D) chunks; blocks of one cell block are placed on one XCD so that those
+// re-reads are L2 / Infinity-Cache hits and HBM sees every byte of x about once.
+// ------------------------------------------------------------------------------------------------
+template <int D, int SCAP, bool SEXACT>
+__global__ void __launch_bounds__(256)
+k_shifting(const float* __restrict__ x, long T, long C, const int* __restrict__ tindex, int n_cal,
+           int first_valid, const int* __restrict__ out_index, const int* __restrict__ rowb_index, int W,
+           int S_rt, int write_clim, const float* __restrict__ edges, int nb, float* __restrict__ out,
+           unsigned short* __restrict__ bins, unsigned char* __restrict__ mask, int* __restrict__ invalid_count,
+           int ncb, int nchunks) {
+    extern __shared__ float lds[];
+    float* ring = lds;                  // [D][W][256]
+    float* e = lds + (size_t)D * W * 256;  // [nb+1] when binning
+
+    int cb, chunk;
+    if (!xcd_swizzle(blockIdx.x, ncb, nchunks, cb, chunk)) return;
+    const int tid = threadIdx.x;
+    const long c = (long)cb * 256 + tid;
+    const bool active = c < C;
+    const int S = SEXACT ? SCAP : S_rt;
+    const int lo = S / 2;
+    const float Sf = (float)S;
+    const int d0 = chunk * D;
+    const int Dv = (NDOY - d0) < D ? (NDOY - d0) : D;
+    const bool do_bins = bins != nullptr;
+
+    for (int i = tid; i < D * W * 256; i += 256) ring[i] = nan_f();
+    if (do_bins)
+        for (int i = tid; i <= nb; i += 256) e[i] = edges[i];
+    __syncthreads();
+    float inv_width = 0.f;
+    if (do_bins) inv_width = (float)(nb - 1) / (e[nb] - e[1]);
+
+    int n_invalid = 0;
+    if (chunk == 0 && mask && active) mask[c] = finite_f(x[c]) ? 1 : 0;
+
+    // one (dayofyear i, year y) element: climatology from the ring, anomaly, bin, then push s into the ring
+    auto emit = [&](int i, int y, int t, float xc, float s) {
+        float* col = ring + (size_t)i * W * 256 + tid;
+        const int slot0 = y % W;
+        if (t >= 0) {
+            if (!finite_f(xc)) ++n_invalid;
+            if (y >= first_valid) {
+                const int oi = out_index[t];
+                if (oi >= 0) {
+                    float clim = nan_f();
+                    if (write_clim || xc == xc) {
+                        // years y-W .. y-1 in ascending order = slots slot0, slot0+1, ... (mod W)
+                        float acc = 0.f;
+                        int sl = slot0;
+                        for (int j = 0; j < W; ++j) {
+                            acc += col[sl * 256];
+                            sl = (sl + 1 == W) ? 0 : sl + 1;
+                        }
+                        int n = W;
+                        if (!(acc == acc)) {  // a NaN term: redo as nanmean
+                            acc = 0.f;
+                            n = 0;
+                            sl = slot0;
+                            for (int j = 0; j < W; ++j) {
+                                float v = col[sl * 256];
+                                if (v == v) {
+                                    acc += v;
+                                    ++n;
+                                }
+                                sl = (sl + 1 == W) ? 0 : sl + 1;
+                            }
+                        }
+                        clim = acc / (float)n;  // n == 0 -> 0/0 = NaN
+                    }
+                    if (active) {
+                        const float a = xc - clim;
+                        out[(size_t)oi * C + c] = write_clim ? clim : a;
+                        if (do_bins) {
+                            const int rb = rowb_index[t];
+                            bins[(size_t)rb * C + c] = (unsigned short)digitize_bin(a, e, nb, inv_width);
+                        }
+                    }
+                }
+            }
+        }
+        col[slot0 * 256] = (t >= 0) ? s : nan_f();
+    };
+
+    float xw[D + SCAP - 1];
+    for (int y = 0; y < n_cal; ++y) {
+        const int* trow = tindex + (size_t)y * NDOY + d0;
+        int tt[D];
+        bool fast = true, any = false;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            tt[i] = (i < Dv) ? trow[i] : -1;
+            if (i < Dv) {
+                any |= tt[i] >= 0;
+                fast &= (tt[i] >= 0) && (tt[i] == tt[0] + i);
+            }
+        }
+        if (!any && y < W) continue;  // nothing to read, and the ring slot of this year still holds its initial NaN
+        if (fast) {
+            const long r0 = (long)tt[0] - lo;
+            const int nload = Dv + S - 1;
+#pragma unroll
+            for (int j = 0; j < D + SCAP - 1; ++j) {
+                float v = nan_f();
+                if (j < nload) {
+                    const long row = r0 + j;
+                    if (active && row >= 0 && row < T) v = x[(size_t)row * C + c];
+                }
+                xw[j] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                if (i < Dv) {
+                    float acc = xw[i];
+                    float xc = (lo == 0) ? xw[i] : 0.f;
+#pragma unroll
+                    for (int k = 1; k < SCAP; ++k) {
+                        if (k < S) {
+                            acc += xw[i + k];
+                            if (k == lo) xc = xw[i + k];
+                        }
+                    }
+                    emit(i, y, tt[i], xc, acc / Sf);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                if (i < Dv) {
+                    float xc = nan_f(), s = nan_f();
+                    if (tt[i] >= 0) {
+                        const long r0 = (long)tt[i] - lo;
+#pragma unroll
+                        for (int k = 0; k < SCAP; ++k) {
+                            float v = nan_f();
+                            if (k < S) {
+                                const long row = r0 + k;
+                                if (active && row >= 0 && row < T) v = x[(size_t)row * C + c];
+                            }
+                            xw[k] = v;
+                        }
+                        float acc = xw[0];
+                        xc = (lo == 0) ? xw[0] : 0.f;
+#pragma unroll
+                        for (int k = 1; k < SCAP; ++k) {
+                            if (k < S) {
+                                acc += xw[k];
+                                if (k == lo) xc = xw[k];
+                            }
+                        }
+                        s = acc / Sf;
+                    }
+                    emit(i, y, tt[i], xc, s);
+                }
+            }
+        }
+    }
+    if (invalid_count && active && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
+}
+
+template <int D, int SCAP, bool SEXACT>
+static int launch_shifting(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* tindex, int n_cal,
+                           int first_valid, const int32_t* out_index, const int32_t* rowb_index, int W, int S,
+                           int write_clim, const float* edges, int nb, float* out, uint16_t* bins, uint8_t* mask,
+                           int32_t* invalid_count) {
+    const int ncb = (int)((C + 255) / 256);
+    const int nchunks = (NDOY + D - 1) / D;
+    const size_t lds = ((size_t)D * W * 256 + (bins ? (size_t)nb + 1 : 0)) * sizeof(float);
+    auto kern = k_shifting<D, SCAP, SEXACT>;
+    if (lds > 48 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        LaunchTimer lt(ctx, MAREX_K_SHIFTING);
+        hipLaunchKernelGGL(kern, dim3(xcd_grid(ncb, nchunks)), dim3(256), lds, ctx->stream, x, (long)T, (long)C,
+                           tindex, n_cal, first_valid, out_index, rowb_index, W, S, write_clim, edges, nb, out,
+                           bins, mask, invalid_count, ncb, nchunks);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+template <int SCAP, bool SEXACT>
+static int dispatch_shifting_D(int D, marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* tindex,
+                               int n_cal, int first_valid, const int32_t* out_index, const int32_t* rowb_index,
+                               int W, int S, int write_clim, const float* edges, int nb, float* out,
+                               uint16_t* bins, uint8_t* mask, int32_t* invalid_count) {
+#define MAREX_ARGS ctx, x, T, C, tindex, n_cal, first_valid, out_index, rowb_index, W, S, write_clim, edges, nb, out, bins, mask, invalid_count
+    switch (D) {
+        case 8: return launch_shifting<8, SCAP, SEXACT>(MAREX_ARGS);
+        case 4: return launch_shifting<4, SCAP, SEXACT>(MAREX_ARGS);
+        case 2: return launch_shifting<2, SCAP, SEXACT>(MAREX_ARGS);
+        default: return launch_shifting<1, SCAP, SEXACT>(MAREX_ARGS);
+    }
+#undef MAREX_ARGS
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
+                                           const int32_t* tindex, int n_cal_years, int first_valid_year,
+                                           const int32_t* out_index, const int32_t* rowb_index, int W, int S,
+                                           int write_clim, const float* edges, int nb, float* out, uint16_t* bins,
+                                           uint8_t* mask, int32_t* invalid_count) {
+    if (!ctx) return -1;
+    if (!x || !tindex || !out_index || !out || T <= 0 || C <= 0 || n_cal_years <= 0)
+        return fail(ctx, -1, "marex_shifting_baseline_f32: null pointer or empty shape");
+    if (W < 1 || S < 1) return fail(ctx, -1, "marex_shifting_baseline_f32: W and S must be >= 1");
+    if (S > 128) return fail(ctx, -4, "marex_shifting_baseline_f32: smooth_days_baseline > 128 is not supported");
+    if (bins && (!edges || !rowb_index || nb < 4 || nb > 65534))
+        return fail(ctx, -1, "marex_shifting_baseline_f32: binning needs edges, rowb_index and 4 <= nb <= 65534");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // largest dayofyear chunk whose LDS ring leaves room for two workgroups per CU
+    const size_t budget = 72 * 1024, extra = bins ? ((size_t)nb + 1) * 4 : 0;
+    int D = env_int("MAREX_SHIFT_D", 0);
+    if (D != 1 && D != 2 && D != 4 && D != 8) {
+        D = 4;
+        while (D > 1 && (size_t)D * W * 1024 + extra > budget) D >>= 1;
+    }
+    if ((size_t)D * W * 1024 + extra > 160 * 1024)
+        return fail(ctx, -4, "marex_shifting_baseline_f32: window_year_baseline=%d needs more than 160 KiB of LDS", W);
+#define MAREX_ARGS D, ctx, x, T, C, tindex, n_cal_years, first_valid_year, out_index, rowb_index, W, S, write_clim, edges, nb, out, bins, mask, invalid_count
+    if (S == 21) return dispatch_shifting_D<21, true>(MAREX_ARGS);
+    if (S <= 8) return dispatch_shifting_D<8, false>(MAREX_ARGS);
+    if (S <= 32) return dispatch_shifting_D<32, false>(MAREX_ARGS);
+    if (S <= 64) return dispatch_shifting_D<64, false>(MAREX_ARGS);
+    return dispatch_shifting_D<128, false>(MAREX_ARGS);
+#undef MAREX_ARGS
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_T: day-of-year thresholds from pooled histograms
+//
+// Workgroup = NSEG consecutive cells of one grid row.  It keeps the pooled (ws x ws cells, wd days)
+// histogram of every output cell in LDS and slides it over the day-of-year axis: entering the next
+// day adds one dayofyear bucket of every input cell of the neighbourhood and removes the one that
+// leaves the window (integer counts, order independent => exact).  The quantile bin `iu` and the
+// count below it are tracked incrementally instead of re-scanning the nb bins.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ordered_key(float v) {
+    unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ void __launch_bounds__(256)
+k_thresholds(const unsigned short* __restrict__ bins, long C, int ny, int nx, int nseg_per_row, int NSEG,
+             const int* __restrict__ doy_start, const float* __restrict__ first_anom,
+             const float* __restrict__ centres, int nb, double q, int wd, int p, float lower_bound,
+             float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats) {
+    extern __shared__ unsigned lds_u[];
+    unsigned* hist = lds_u;                      // [NSEG][nb]
+    int* st_iu = (int*)(hist + (size_t)NSEG * nb);  // [NSEG]
+    int* st_below = st_iu + NSEG;                // [NSEG]
+    int* st_tot = st_below + NSEG;               // [NSEG]
+
+    const int tid = threadIdx.x;
+    const int j = (ny > 0) ? (int)(blockIdx.x / nseg_per_row) : 0;
+    const int seg = (int)(blockIdx.x % nseg_per_row);
+    const int i0 = seg * NSEG;
+    const int nout = (nx - i0) < NSEG ? (nx - i0) : NSEG;
+    const int jlo = (j - p) < 0 ? 0 : j - p;
+    const int jhi = (ny > 0) ? ((j + p) > ny - 1 ? ny - 1 : j + p) : 0;
+    const int R = jhi - jlo + 1;
+    const int win = nout + 2 * p;          // input columns i0-p .. i0+nout-1+p (lon periodic)
+    const int ncell_in = R * win;
+    const int pd = wd / 2;
+
+    for (int i = tid; i < NSEG * nb; i += 256) hist[i] = 0u;
+    for (int i = tid; i < 3 * NSEG; i += 256) st_iu[i] = 0;
+    __syncthreads();
+
+    // add (sgn=+1) or remove (sgn=-1) the samples of dayofyear `d1` (1-based) of the whole neighbourhood
+    auto apply_bucket = [&](int d1, int sgn) {
+        const int r0 = doy_start[d1 - 1], r1 = doy_start[d1];
+        for (int ic = tid; ic < ncell_in; ic += 256) {
+            const int rr = ic / win, ii = ic - rr * win;
+            int gi = (i0 - p + ii) % nx;
+            if (gi < 0) gi += nx;
+            const long cell = (long)(jlo + rr) * nx + gi;
+            int o_lo = ii - 2 * p;
+            if (o_lo < 0) o_lo = 0;
+            int o_hi = ii < nout - 1 ? ii : nout - 1;
+            for (int r = r0; r < r1; ++r) {
+                const int b = bins[(size_t)r * C + cell];
+                if (b >= nb) continue;
+                for (int o = o_lo; o <= o_hi; ++o) {
+                    atomicAdd(&hist[(size_t)o * nb + b], (unsigned)sgn);
+                    atomicAdd(&st_tot[o], sgn);
+                    if (b < st_iu[o]) atomicAdd(&st_below[o], sgn);
+                }
+            }
+        }
+    };
+
+    for (int o = -pd; o <= pd; ++o) apply_bucket(((0 + o) % NDOY + NDOY) % NDOY + 1, +1);
+    __syncthreads();
+
+    unsigned kmin = 0xFFFFFFFFu, kmax = 0u, nlow = 0u, nhigh = 0u;
+    for (int d = 0; d < NDOY; ++d) {
+        if (d > 0) {
+            apply_bucket((d + pd) % NDOY + 1, +1);
+            apply_bucket(((d - pd - 1) % NDOY + NDOY) % NDOY + 1, -1);
+            __syncthreads();
+        }
+        if (tid < nout) {
+            const unsigned* h = hist + (size_t)tid * nb;
+            const int tot = st_tot[tid];
+            int iu = st_iu[tid], below = st_below[tid];
+            const double qpos = q * (double)tot;
+            float t32 = nan_f();
+            if (tot > 0) {
+                while (iu < nb - 1 && (double)(below + (int)h[iu]) <= qpos) {
+                    below += (int)h[iu];
+                    ++iu;
+                }
+                while (iu > 0 && (double)below > qpos) {
+                    --iu;
+                    below -= (int)h[iu];
+                }
+                const int il = iu > 0 ? iu - 1 : 0;
+                const int cs_iu = below + (int)h[iu];
+                const int cs_il = iu > 0 ? below : cs_iu;
+                const int diff = cs_iu - cs_il;
+                const double frac = diff > 0 ? (qpos - (double)cs_il) / (double)diff : 0.5;
+                const float dc = centres[iu] - centres[il];
+                const double prod = frac * (double)dc;
+                t32 = (float)((double)centres[il] + prod);
+                if (iu == 0) t32 = centres[0];
+            } else {
+                iu = 0;
+                below = 0;
+            }
+            st_iu[tid] = iu;
+            st_below[tid] = below;
+            const long cell = (long)j * nx + i0 + tid;
+            if (!(first_anom[cell] == first_anom[cell])) t32 = nan_f();
+            if (t32 == t32) {
+                const unsigned k = ordered_key(t32);
+                kmin = k < kmin ? k : kmin;
+                kmax = k > kmax ? k : kmax;
+                if (t32 > upper_bound) ++nhigh;
+                if (t32 < lower_bound) {
+                    ++nlow;
+                    t32 = lower_bound;
+                }
+            }
+            thr[(size_t)d * C + cell] = t32;
+        }
+        __syncthreads();
+    }
+    if (tid < nout) {
+        if (kmin != 0xFFFFFFFFu) atomicMin(&stats->min_key, kmin);
+        if (kmax != 0u) atomicMax(&stats->max_key, kmax);
+        if (nlow) atomicAdd(&stats->n_too_low, nlow);
+        if (nhigh) atomicAdd(&stats->n_too_high, nhigh);
+    }
+}
+
+extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins, int64_t T_out, int64_t C, int ny,
+                                           int nx, const int32_t* doy_start, const float* first_anom,
+                                           const float* centres, int nb, double q, int wd, int ws,
+                                           float lower_bound, float upper_bound, float* thr_doy_major,
+                                           marex_thr_stats* stats) {
+    if (!ctx) return -1;
+    if (!bins || !doy_start || !first_anom || !centres || !thr_doy_major || !stats || T_out <= 0 || C <= 0)
+        return fail(ctx, -1, "marex_hobday_thresholds_f32: null pointer or empty shape");
+    if (wd < 3 || wd > 365 || (wd & 1) == 0)
+        return fail(ctx, -1, "marex_hobday_thresholds_f32: window_days_hobday must be odd and in 3..365");
+    if (ws < 1 || (ws & 1) == 0) return fail(ctx, -1, "marex_hobday_thresholds_f32: window_spatial_hobday must be odd");
+    if (!(q > 0.0 && q <= 1.0)) return fail(ctx, -1, "marex_hobday_thresholds_f32: q must be in (0, 1]");
+    if (ny == 0) {
+        if (ws > 1) return fail(ctx, -1, "marex_hobday_thresholds_f32: spatial pooling needs a structured grid");
+        nx = (int)C;
+    } else if ((int64_t)ny * nx != C) {
+        return fail(ctx, -1, "marex_hobday_thresholds_f32: ny*nx != C");
+    }
+    if (nb < 4 || nb > 36000) return fail(ctx, -4, "marex_hobday_thresholds_f32: nb must be in 4..36000");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int NSEG = env_int("MAREX_THR_NSEG", 32);
+    const size_t budget = 72 * 1024;
+    while (NSEG > 1 && (size_t)NSEG * (nb + 3) * 4 > budget) NSEG >>= 1;
+    if (NSEG > nx) NSEG = nx;
+    const size_t lds = (size_t)NSEG * (nb + 3) * 4;
+    const int nseg_per_row = (nx + NSEG - 1) / NSEG;
+    const unsigned nblocks = (unsigned)nseg_per_row * (unsigned)(ny > 0 ? ny : 1);
+    if (lds > 48 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_thresholds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
+        hipLaunchKernelGGL(k_thresholds, dim3(nblocks), dim3(256), lds, ctx->stream, bins, (long)C, ny, nx,
+                           nseg_per_row, NSEG, doy_start, first_anom, centres, nb, q, wd, ws / 2, lower_bound,
+                           upper_bound, thr_doy_major, stats);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_M: extreme[t, c] = anom[t, c] >= thr[doy(t), c]
+// One workgroup = (VEC*256 cells, one dayofyear): the threshold row is read once and reused for all
+// timesteps of that dayofyear; 16-byte loads of the anomaly row, 4-byte stores of the mask.
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256)
+k_mask_ge(const float* __restrict__ anom, const float* __restrict__ thr, const int* __restrict__ doy_start,
+          const int* __restrict__ doy_rows, long C, unsigned char* __restrict__ out,
+          unsigned long long* __restrict__ n_true) {
+    const int d = blockIdx.y;
+    const long c = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    const int r0 = doy_start[d], r1 = doy_start[d + 1];
+    unsigned cnt = 0;
+    if (c < C) {
+        if (VEC == 4) {
+            const float4 th = *reinterpret_cast<const float4*>(thr + (size_t)d * C + c);
+#pragma unroll 4
+            for (int r = r0; r < r1; ++r) {
+                const size_t off = (size_t)doy_rows[r] * C + c;
+                const float4 a = *reinterpret_cast<const float4*>(anom + off);
+                uchar4 m;
+                m.x = a.x >= th.x;
+                m.y = a.y >= th.y;
+                m.z = a.z >= th.z;
+                m.w = a.w >= th.w;
+                cnt += m.x + m.y + m.z + m.w;
+                *reinterpret_cast<uchar4*>(out + off) = m;
+            }
+        } else {
+            const float th = thr[(size_t)d * C + c];
+            for (int r = r0; r < r1; ++r) {
+                const size_t off = (size_t)doy_rows[r] * C + c;
+                const unsigned char m = anom[off] >= th;
+                cnt += m;
+                out[off] = m;
+            }
+        }
+    }
+    if (n_true) {
+        for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s, 64);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(n_true, (unsigned long long)cnt);
+    }
+}
+
+extern "C" int marex_mask_ge_doy_f32(marex_ctx* ctx, const float* anom, const float* thr_doy_major,
+                                     const int32_t* doy_start, const int32_t* doy_rows, int64_t T_out, int64_t C,
+                                     uint8_t* extreme, unsigned long long* n_true) {
+    if (!ctx) return -1;
+    if (!anom || !thr_doy_major || !doy_start || !doy_rows || !extreme || T_out <= 0 || C <= 0)
+        return fail(ctx, -1, "marex_mask_ge_doy_f32: null pointer or empty shape");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool vec = (C % 4 == 0) && (((uintptr_t)anom | (uintptr_t)thr_doy_major) % 16 == 0) && ((uintptr_t)extreme % 4 == 0);
+    {
+        LaunchTimer lt(ctx, MAREX_K_MASK);
+        if (vec) {
+            dim3 grid((unsigned)((C / 4 + 255) / 256), NDOY);
+            hipLaunchKernelGGL(k_mask_ge<4>, grid, dim3(256), 0, ctx->stream, anom, thr_doy_major, doy_start, doy_rows,
+                               (long)C, extreme, n_true);
+        } else {
+            dim3 grid((unsigned)((C + 255) / 256), NDOY);
+            hipLaunchKernelGGL(k_mask_ge<1>, grid, dim3(256), 0, ctx->stream, anom, thr_doy_major, doy_start, doy_rows,
+                               (long)C, extreme, n_true);
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// transpose (thresholds [366, C] -> [C, 366])
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ in, long rows, long cols,
+                                                   float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const long c0 = (long)blockIdx.x * 32, r0 = (long)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const long r = r0 + k, c = c0 + tx;
+        if (r < rows && c < cols) tile[k][tx] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const long c = c0 + k, r = r0 + tx;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][k];
+    }
+}
+
+extern "C" int marex_transpose_f32(marex_ctx* ctx, const float* in, int64_t rows, int64_t cols, float* out) {
+    if (!ctx) return -1;
+    if (!in || !out || rows <= 0 || cols <= 0) return fail(ctx, -1, "marex_transpose_f32: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    {
+        LaunchTimer lt(ctx, MAREX_K_TRANSPOSE);
+        hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, ctx->stream, in, (long)rows, (long)cols, out);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

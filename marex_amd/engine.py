@@ -1,0 +1,226 @@
+"""Device pipeline of the hot path: torch owns HBM buffers and streams, the HIP library does the work.
+
+``HotPath`` is the array-level engine underneath :func:`marex_amd.detect.preprocess_data`.  It takes
+``[T, C]`` float32 device tensors (C-order ``(time, cells)`` exactly like the reference's
+``(time, lat, lon)`` arrays) plus the host calendar / bin tables and calls the C ABI
+(``include/marex_hip.h``) stage by stage.  No stage has a CPU implementation here.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .binning import BinTable
+from .calendar import N_DOY, CalendarPlan
+from .exceptions import ConfigurationError, ProcessingError
+
+
+def _key_to_float(key: int) -> float:
+    """Inverse of the order-preserving uint32 key used for the device-side min / max of thresholds."""
+    bits = (key & 0x7FFFFFFF) if (key & 0x80000000) else (~key & 0xFFFFFFFF)
+    return float(np.array([bits], dtype=np.uint32).view(np.float32)[0])
+
+
+@dataclass
+class DeviceCalendar:
+    """Calendar tables resident on the device."""
+
+    tindex: torch.Tensor
+    out_index: torch.Tensor
+    rowb_index: torch.Tensor
+    doy_start: torch.Tensor
+    doy_rows: torch.Tensor
+    plan: CalendarPlan
+
+
+class HotPath:
+    def __init__(self, device: int | torch.device = 0):
+        if not torch.cuda.is_available():
+            raise ProcessingError(
+                "marex_amd needs a HIP device (torch.cuda.is_available() is False)",
+                details="the hot path has no CPU implementation",
+            )
+        self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
+        self.ctx = _lib.Context(self.device.index)
+        self.lib = self.ctx.lib
+        self._bind_stream()
+
+    # ------------------------------------------------------------------ plumbing
+    def _bind_stream(self) -> None:
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a: np.ndarray, dtype=None) -> torch.Tensor:
+        t = torch.from_numpy(np.ascontiguousarray(a if dtype is None else a.astype(dtype)))
+        return t.to(self.device, non_blocking=False)
+
+    def upload_calendar(self, cal: CalendarPlan) -> DeviceCalendar:
+        return DeviceCalendar(
+            tindex=self._dev(cal.tindex, np.int32),
+            out_index=self._dev(cal.out_index, np.int32),
+            rowb_index=self._dev(cal.rowb_index, np.int32),
+            doy_start=self._dev(cal.doy_start, np.int32),
+            doy_rows=self._dev(cal.doy_rows, np.int32),
+            plan=cal,
+        )
+
+    def sync(self) -> None:
+        self.ctx.sync()
+
+    # ------------------------------------------------------------------ synthetic field
+    def synth_field(self, tab, cell_base: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Device evaluation of :func:`marex_amd.synth.synth_field` (bit-identical)."""
+        self._bind_stream()
+        T, Cn = tab.T, tab.C
+        if out is None:
+            out = torch.empty((T, Cn), dtype=torch.float32, device=self.device)
+        bufs = [
+            self._dev(tab.mean, np.float32), self._dev(tab.amp, np.float32), self._dev(tab.hemi, np.uint8),
+            self._dev(tab.land, np.uint8), self._dev(tab.seas, np.float32), self._dev(tab.trend, np.float32),
+        ]
+        rc = self.lib.marex_synth_sst_f32(
+            self.ctx.handle, *[b.data_ptr() for b in bufs], tab.seed, int(cell_base), T, Cn, out.data_ptr()
+        )
+        self.ctx.check(rc, "marex_synth_sst_f32")
+        self.sync()  # the small tables above must outlive the kernel
+        return out
+
+    # ------------------------------------------------------------------ stage a3+a5+a6+a7 (+a10 binning)
+    def shifting_baseline(
+        self,
+        x: torch.Tensor,
+        dcal: DeviceCalendar,
+        W: int,
+        S: int,
+        bins: Optional[BinTable] = None,
+        write_clim: bool = False,
+    ) -> Dict[str, torch.Tensor]:
+        self._bind_stream()
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+        T, Cn = x.shape
+        cal = dcal.plan
+        if cal.T != T:
+            raise ProcessingError("calendar length does not match the time axis of x")
+        if cal.has_duplicates:
+            raise ConfigurationError(
+                "shifting_baseline needs at most one timestep per (year, dayofyear)",
+                details="sub-daily time axes are not supported by the device path",
+            )
+        T_out = cal.T_out
+        out = torch.empty((T_out, Cn), dtype=torch.float32, device=self.device)
+        if write_clim:
+            out.fill_(float("nan"))
+        mask = torch.empty((Cn,), dtype=torch.uint8, device=self.device)
+        invalid = torch.zeros((Cn,), dtype=torch.int32, device=self.device)
+        if bins is not None and not write_clim:
+            edges = self._dev(bins.edges, np.float32)
+            binsb = torch.empty((T_out, Cn), dtype=torch.int16, device=self.device)
+            e_ptr, b_ptr, nb = edges.data_ptr(), binsb.data_ptr(), bins.nb
+        else:
+            edges = binsb = None
+            e_ptr, b_ptr, nb = None, None, 0
+        rc = self.lib.marex_shifting_baseline_f32(
+            self.ctx.handle, x.data_ptr(), T, Cn, dcal.tindex.data_ptr(), cal.n_cal_years, int(W),
+            dcal.out_index.data_ptr(), dcal.rowb_index.data_ptr(), int(W), int(S), int(write_clim),
+            e_ptr, nb, out.data_ptr(), b_ptr, mask.data_ptr(), invalid.data_ptr(),
+        )
+        self.ctx.check(rc, "marex_shifting_baseline_f32")
+        res = {"out": out, "mask": mask, "invalid_count": invalid, "_keep": edges}
+        if binsb is not None:
+            res["bins"] = binsb
+        return res
+
+    # ------------------------------------------------------------------ stage a10/a11
+    def hobday_thresholds(
+        self,
+        binsb: torch.Tensor,
+        first_anom: torch.Tensor,
+        dcal: DeviceCalendar,
+        bins: BinTable,
+        q: float,
+        wd: int,
+        ws: int,
+        ny: int,
+        nx: int,
+    ) -> Dict[str, object]:
+        self._bind_stream()
+        T_out, Cn = binsb.shape
+        thr = torch.empty((N_DOY, Cn), dtype=torch.float32, device=self.device)
+        stats = torch.tensor([0xFFFFFFFF - (1 << 32), 0, 0, 0], dtype=torch.int32, device=self.device)
+        centres = self._dev(bins.centres, np.float32)
+        rc = self.lib.marex_hobday_thresholds_f32(
+            self.ctx.handle, binsb.data_ptr(), T_out, Cn, int(ny), int(nx), dcal.doy_start.data_ptr(),
+            first_anom.data_ptr(), centres.data_ptr(), bins.nb, float(q), int(wd), int(ws),
+            float(bins.lower_bound), float(bins.upper_bound), thr.data_ptr(), stats.data_ptr(),
+        )
+        self.ctx.check(rc, "marex_hobday_thresholds_f32")
+        return {"thr_doy_major": thr, "stats_dev": stats, "_keep": centres}
+
+    @staticmethod
+    def decode_thr_stats(stats_dev: torch.Tensor) -> Dict[str, float]:
+        s = stats_dev.cpu().numpy().view(np.uint32)
+        kmin, kmax = int(s[0]), int(s[1])
+        return {
+            "min": _key_to_float(kmin) if kmin != 0xFFFFFFFF else float("nan"),
+            "max": _key_to_float(kmax) if kmax != 0 else float("nan"),
+            "n_too_low": int(s[2]),
+            "n_too_high": int(s[3]),
+        }
+
+    # ------------------------------------------------------------------ stage a9 compare
+    def mask_ge_doy(self, anom: torch.Tensor, thr_doy_major: torch.Tensor, dcal: DeviceCalendar) -> Dict[str, torch.Tensor]:
+        self._bind_stream()
+        T_out, Cn = anom.shape
+        ext = torch.empty((T_out, Cn), dtype=torch.uint8, device=self.device)
+        n_true = torch.zeros((1,), dtype=torch.int64, device=self.device)
+        rc = self.lib.marex_mask_ge_doy_f32(
+            self.ctx.handle, anom.data_ptr(), thr_doy_major.data_ptr(), dcal.doy_start.data_ptr(),
+            dcal.doy_rows.data_ptr(), T_out, Cn, ext.data_ptr(), n_true.data_ptr(),
+        )
+        self.ctx.check(rc, "marex_mask_ge_doy_f32")
+        return {"extreme": ext, "n_true": n_true}
+
+    def transpose(self, a: torch.Tensor) -> torch.Tensor:
+        self._bind_stream()
+        rows, cols = a.shape
+        out = torch.empty((cols, rows), dtype=torch.float32, device=self.device)
+        self.ctx.check(self.lib.marex_transpose_f32(self.ctx.handle, a.data_ptr(), rows, cols, out.data_ptr()), "marex_transpose_f32")
+        return out
+
+    # ------------------------------------------------------------------ whole path (shifting + hobday approx)
+    def shifting_hobday(
+        self,
+        x: torch.Tensor,
+        dcal: DeviceCalendar,
+        *,
+        W: int,
+        S: int,
+        bins: BinTable,
+        q: float,
+        wd: int,
+        ws: int,
+        ny: int,
+        nx: int,
+        transpose_thresholds: bool = True,
+    ) -> Dict[str, object]:
+        """validation + anomaly + thresholds + mask for ``shifting_baseline`` / ``hobday_extreme`` (approximate)."""
+        a = self.shifting_baseline(x, dcal, W, S, bins)
+        t = self.hobday_thresholds(a["bins"], a["out"], dcal, bins, q, wd, ws, ny, nx)
+        m = self.mask_ge_doy(a["out"], t["thr_doy_major"], dcal)
+        res = {
+            "dat_anomaly": a["out"],
+            "mask": a["mask"],
+            "invalid_count": a["invalid_count"],
+            "thr_doy_major": t["thr_doy_major"],
+            "stats_dev": t["stats_dev"],
+            "extreme_events": m["extreme"],
+            "n_true": m["n_true"],
+            "_keep": (a["_keep"], t["_keep"], a.get("bins")),
+        }
+        if transpose_thresholds:
+            res["thresholds"] = self.transpose(t["thr_doy_major"])
+        return res

@@ -1,0 +1,134 @@
+"""Generate golden vectors from the REAL reference (runs only in the build container).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py
+
+The reference package cannot be imported as a whole here (dask / xarray / flox /
+xhistogram are not installed), but ``marEx/detect.py`` loads under inert stubs for
+those modules.  Two of its functions are then *real* code
+with no third-party dependency beyond NumPy:
+
+* ``_rolling_histogram_quantile``  (detect.py:2465-2559)  -> hist_quantile_goldens.npz
+* ``_get_preprocessing_steps``     (detect.py:844-888)    -> preprocessing_steps.json
+
+Only inputs and expected outputs are written; no reference source travels.
+Nothing under /root/reference is modified.
+"""
+
+import importlib.util
+import itertools
+import json
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/marEx"
+
+
+def load_reference_detect():
+    sys.dont_write_bytecode = True
+    for name in [
+        "dask", "dask.base", "dask.array", "dask.distributed", "distributed", "dask_jobqueue",
+        "flox", "flox.xarray", "xarray", "xhistogram", "xhistogram.xarray",
+    ]:
+        sys.modules[name] = MagicMock(name=name)
+    pkg = types.ModuleType("marEx")
+    pkg.__path__ = [REF]
+    sys.modules["marEx"] = pkg
+
+    def load(mod):
+        spec = importlib.util.spec_from_file_location("marEx." + mod, f"{REF}/{mod}.py")
+        m = importlib.util.module_from_spec(spec)
+        sys.modules["marEx." + mod] = m
+        spec.loader.exec_module(m)
+        return m
+
+    for m in ("exceptions", "logging_config", "helper"):
+        load(m)
+    return load("detect")
+
+
+def make_hists(nb, rng):
+    """Histogram regimes [366, nb] (uint16), bin 0 = everything below -precision."""
+    out = {}
+
+    def from_samples(gen, n_per_doy):
+        edges = np.concatenate([[-np.inf], np.arange(-0.01, 5.0 + 0.01, 0.01, dtype=np.float32)], dtype=np.float32)
+        h = np.zeros((366, nb), dtype=np.uint16)
+        for d in range(366):
+            n = n_per_doy if d < 365 else max(1, n_per_doy // 4)
+            v = gen(n).astype(np.float32)
+            b = np.digitize(v, edges) - 1
+            b = b[b < nb]
+            np.add.at(h[d], b, 1)
+        return h
+
+    out["normal40"] = from_samples(lambda n: rng.normal(0, 1, n), 40)
+    out["normal_pooled"] = from_samples(lambda n: rng.normal(0.1, 0.8, n), 40 * 25)
+    out["uniform"] = from_samples(lambda n: rng.uniform(-2, 4, n), 30)
+    out["sparse_tail"] = from_samples(lambda n: rng.normal(-1.5, 0.6, n), 12)
+    out["all_negative"] = from_samples(lambda n: -np.abs(rng.normal(1, 0.3, n)) - 0.02, 20)
+    out["beyond_range"] = from_samples(lambda n: rng.normal(4.5, 1.0, n), 25)
+    const = np.zeros((366, nb), dtype=np.uint16)
+    const[:, 2] = 17  # constant anomaly 0.0 -> bin [0, 0.01)
+    out["constant_zero"] = const
+    empty = out["normal40"].copy()
+    empty[100:140] = 0  # dayofyear rows without any sample (window totals reach 0 in the middle)
+    out["empty_doys"] = empty
+    last = np.zeros((366, nb), dtype=np.uint16)
+    last[:, nb - 1] = 9
+    out["last_bin_only"] = last
+    return out
+
+
+def main():
+    detect = load_reference_detect()
+    rng = np.random.default_rng(20240607)
+    edges = np.concatenate([[-np.inf], np.arange(-0.01, 5.0 + 0.01, 0.01, dtype=np.float32)], dtype=np.float32)
+    centres = (edges[1:] + edges[:-1]) / 2
+    centres[0] = 0.0
+    centres = centres.astype(np.float32)
+    nb = centres.size
+
+    hists = make_hists(nb, rng)
+    payload = {"centres": centres, "edges": edges}
+    cases = []
+    for (name, h), wd, q in itertools.product(hists.items(), (3, 5, 11, 21, 41), (0.6, 0.9, 0.95, 0.99)):
+        for dt in ("uint16", "float64"):
+            key = f"{name}|wd{wd}|q{q}|{dt}"
+            payload["out|" + key] = detect._rolling_histogram_quantile(h.astype(dt), wd, q, centres)
+            cases.append(key)
+    # custom (coarser) bin centres, float64 centres as in the docstring's type hint
+    c64 = np.linspace(0.0, 5.0, nb)
+    for wd, q in ((11, 0.95), (5, 0.9)):
+        key = f"normal40|wd{wd}|q{q}|uint16|centres64"
+        payload["out|" + key] = detect._rolling_histogram_quantile(hists["normal40"], wd, q, c64)
+        cases.append(key)
+    payload["centres64"] = c64
+    for name, h in hists.items():
+        payload["hist|" + name] = h
+    payload["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "hist_quantile_goldens.npz"), **payload)
+
+    steps = []
+    for ma in ("detrend_harmonic", "shifting_baseline", "fixed_baseline", "detrend_fixed_baseline"):
+        for me in ("global_extreme", "hobday_extreme"):
+            for std in (False, True):
+                for ws in (None, 5):
+                    for ref in (None, (1990, 2010)):
+                        args = dict(
+                            method_anomaly=ma, method_extreme=me, std_normalise=std, detrend_orders=[1, 2],
+                            window_year_baseline=15, smooth_days_baseline=21, window_days_hobday=11,
+                            window_spatial_hobday=ws, reference_period=ref,
+                        )
+                        steps.append({"args": args, "steps": detect._get_preprocessing_steps(**args)})
+    with open(os.path.join(HERE, "preprocessing_steps.json"), "w") as f:
+        json.dump(steps, f, indent=1)
+    print(f"wrote {len(cases)} quantile cases and {len(steps)} preprocessing_steps cases")
+
+
+if __name__ == "__main__":
+    main()

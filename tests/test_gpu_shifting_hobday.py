@@ -1,0 +1,112 @@
+"""GPU parity: shifting_baseline + hobday_extreme (approximate) through the C ABI vs the oracle.
+
+Integer / boolean outputs (bins, mask, extreme_events, validation counts) and -- because the arithmetic
+contract fixes every rounding -- the float32 anomalies and thresholds must be BIT-identical.
+"""
+import numpy as np
+import pytest
+import torch
+
+from marex_amd import binning, calendar, synth
+from oracle import marex_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _same_f32(got, exp):
+    """Equal as numbers (NaN == NaN, -0 == +0)."""
+    got = np.asarray(got, dtype=np.float32)
+    exp = np.asarray(exp, dtype=np.float32)
+    return np.array_equal(got, exp, equal_nan=True)
+
+
+def run_case(hot, start, periods, ny, nx, W, S, wd, ws, pct=95.0, unstructured=False, seed=20240607, mutate=None):
+    tm = calendar.daily_time_axis(start, periods)
+    tab = synth.make_tables(tm, 0 if unstructured else ny, nx if not unstructured else ny * nx, seed, unstructured=unstructured)
+    x = synth.synth_field(tab)
+    if mutate is not None:
+        mutate(x)
+    cal = calendar.build_calendar(tm, window_year_baseline=W)
+    bt = binning.hobday_bins()
+    gny, gnx = (0, x.shape[1]) if unstructured else (ny, nx)
+    exp = orc.preprocess_arrays(
+        x, cal, ny=gny, nx=gnx, window_year_baseline=W, smooth_days_baseline=S, window_days_hobday=wd,
+        window_spatial_hobday=ws, threshold_percentile=pct, edges=bt.edges, centres=bt.centres,
+    )
+    dcal = hot.upload_calendar(cal)
+    xd = torch.from_numpy(x).to(hot.device)
+    got = hot.shifting_hobday(xd, dcal, W=W, S=S, bins=bt, q=pct / 100.0, wd=wd, ws=(ws or 1), ny=gny, nx=gnx)
+    hot.sync()
+    return x, cal, bt, exp, got
+
+
+def check_all(x, cal, bt, exp, got):
+    anom = got["dat_anomaly"].cpu().numpy()
+    assert _same_f32(anom, exp["dat_anomaly"]), "anomalies differ from the oracle"
+    assert np.array_equal(got["mask"].cpu().numpy().astype(bool), exp["mask"])
+    v = orc.validate_data_values(x)
+    inv = got["invalid_count"].cpu().numpy()
+    assert np.array_equal(inv, (~np.isfinite(x)).sum(axis=0))
+    assert int(np.where(exp["mask"], inv, 0).max()) == v["max_invalid"]
+    # bins: device rows are dayofyear-sorted
+    bins_exp = orc.digitize_bins(exp["dat_anomaly"], bt.edges)[cal.doy_rows]
+    bins_got = got["_keep"][2].cpu().numpy().view(np.uint16)
+    assert np.array_equal(bins_got, bins_exp)
+    thr = got["thresholds"].cpu().numpy()
+    assert _same_f32(thr, exp["thresholds"]), "thresholds differ from the oracle"
+    ext = got["extreme_events"].cpu().numpy().astype(bool)
+    assert np.array_equal(ext, exp["extreme_events"]), "extreme_events mask differs"
+    assert int(got["n_true"].item()) == int(exp["extreme_events"].sum())
+    from marex_amd.engine import HotPath
+
+    st = HotPath.decode_thr_stats(got["stats_dev"])
+    assert st["n_too_low"] == exp["stats"]["n_too_low"] and st["n_too_high"] == exp["stats"]["n_too_high"]
+    if np.isfinite(exp["stats"]["max"]):
+        assert np.float32(st["max"]) == np.float32(exp["stats"]["max"])
+        assert np.float32(st["min"]) == np.float32(exp["stats"]["min"])
+
+
+def test_gridded_default_windows(hot):
+    """30 yr x 12x16, W=15, S=21, wd=11, ws=5 (the reference defaults for gridded data)."""
+    r = run_case(hot, "1990-01-01", 30 * 365 + 8, 12, 16, 15, 21, 11, 5)
+    check_all(*r)
+    ocean = r[3]["mask"]
+    freq = r[3]["extreme_events"][:, ocean].mean()
+    assert 0.04 < freq < 0.06  # the reference's own pin: 5 % +- 1 % (tests/conftest.py:215-231)
+
+
+def test_gridded_mid_year_start_small_windows(hot):
+    """Series starting mid-year (partial first / last calendar years), W=5, even S, wd=5, ws=3."""
+    r = run_case(hot, "2001-07-19", 12 * 365 + 40, 9, 20, 5, 10, 5, 3, pct=90.0)
+    check_all(*r)
+
+
+def test_unstructured_no_pooling(hot):
+    """(time, ncells) layout, C not a multiple of 4 or 256, no spatial pooling (detect.py:1361-1385)."""
+    r = run_case(hot, "1995-01-01", 20 * 365 + 5, 1, 405, 7, 21, 11, None, unstructured=True)
+    check_all(*r)
+
+
+def test_generic_smoothing_widths(hot):
+    for S in (1, 5, 31):
+        r = run_case(hot, "2000-01-01", 10 * 365 + 3, 5, 8, 4, S, 11, 5, pct=95.0)
+        check_all(*r)
+
+
+def test_weird_cells(hot):
+    """NaN at t=0 but finite later ("land" by the t=0 rule), NaN gaps inside ocean cells, +-inf, constant cells."""
+
+    def mutate(x):
+        ocean = np.flatnonzero(np.isfinite(x[0]))
+        x[:40, ocean[0]] = np.nan          # NaN start -> classified as land, finite later
+        x[500:520, ocean[1]] = np.nan      # gap inside an ocean cell (validation counts it)
+        x[900, ocean[2]] = np.inf
+        x[:, ocean[3]] = np.float32(12.5)  # constant series -> anomaly 0 -> clamp to edges[3]
+        x[:, ocean[4]] += np.float32(40.0) * (np.arange(x.shape[0]) % 7 == 0)  # spikes beyond max_anomaly
+
+    r = run_case(hot, "1998-03-01", 14 * 365 + 4, 6, 12, 6, 21, 11, 5, mutate=mutate)
+    check_all(*r)
