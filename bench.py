@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Benchmark of the preprocess_data hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of validation + shifting-baseline anomaly + day-of-year thresholds + extreme mask
+over one synthetic field that is already resident in HBM.  Metric (BASELINE.json): Mcells*timesteps/s
+(input timesteps), whole job.  Weak scaling: every rank processes one latitude band of `ny_per_gpu`
+rows of a global grid with `N * ny_per_gpu` rows (ingested with ws//2 overlap rows per interior side,
+marex_amd/dist.py); the only collective is an all-reduce of a few int64 scalars.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: 10-yr daily x 1440x720, shifting_baseline (W=5: 10 yr of data cannot
+    # hold the default W=15) + hobday_extreme p95, 5x5 pooling (gridded default)
+    "cfg2": dict(start="2015-01-01", T=3652, ny=720, nx=1440, W=5, S=21, wd=11, ws=5, pct=95.0,
+                 name="10yr-daily x 1440x720 (0.25deg), shifting_baseline(W=5,S=21)+hobday_extreme p95 (wd=11, ws=5)"),
+    # 1/8 of BASELINE.json configs[2] (one of 8 latitude bands of the 100-yr field)
+    "cfg3band": dict(start="1925-01-01", T=36500, ny=90, nx=1440, W=15, S=21, wd=11, ws=5, pct=95.0,
+                     name="100yr-daily x 1440x90 band (1/8 of 0.25deg global), shifting_baseline(W=15,S=21)+hobday_extreme p95"),
+    "tiny": dict(start="2015-01-01", T=3652, ny=48, nx=96, W=5, S=21, wd=11, ws=5, pct=95.0,
+                 name="tiny plumbing case 10yr x 96x48"),
+}
+
+
+def algorithmic_bytes(T, T_out, C):
+    """read 4T (x) + write 4T' (anomaly) + T' (mask) + 4*366 (thresholds) + 1 (mask) per cell."""
+    return C * (4 * T + 5 * T_out + 4 * 366 + 1)
+
+
+def cpu_baseline(wl, seed):
+    """Oracle (NumPy restatement, 1 core) on a bounded sample of the same workload: a 32x64 sub-grid."""
+    from marex_amd import binning, calendar, synth
+    from oracle import marex_oracle as orc
+
+    ny, nx = 32, 64
+    tm = calendar.daily_time_axis(wl["start"], wl["T"])
+    tab = synth.make_tables(tm, ny, nx, seed)
+    x = synth.synth_field(tab)
+    cal = calendar.build_calendar(tm, window_year_baseline=wl["W"])
+    bt = binning.hobday_bins()
+    t0 = time.perf_counter()
+    orc.validate_data_values(x)
+    orc.preprocess_arrays(
+        x, cal, ny=ny, nx=nx, window_year_baseline=wl["W"], smooth_days_baseline=wl["S"],
+        window_days_hobday=wl["wd"], window_spatial_hobday=wl["ws"], threshold_percentile=wl["pct"],
+        edges=bt.edges, centres=bt.centres,
+    )
+    dt = time.perf_counter() - t0
+    return {
+        "value": wl["T"] * ny * nx / 1e6 / dt,
+        "unit": "Mcells*timesteps/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"NumPy oracle on a {ny}x{nx} sub-grid of the same {wl['T']}-day workload ({dt:.1f} s, "
+                  f"host has {os.cpu_count()} cores, 1 used)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--seed", type=int, default=20240607)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from marex_amd import binning, calendar, synth
+    from marex_amd.dist import allreduce_summary, plan_shards
+    from marex_amd.engine import HotPath
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = WORKLOADS[args.workload]
+    T, nx, W = wl["T"], wl["nx"], wl["W"]
+    halo = wl["ws"] // 2
+    shard = plan_shards(wl["ny"] * world, nx, world, halo)[rank]
+
+    hot = HotPath(local_rank)
+    tm = calendar.daily_time_axis(wl["start"], T)
+    cal = calendar.build_calendar(tm, window_year_baseline=W)
+    dcal = hot.upload_calendar(cal)
+    bt = binning.hobday_bins()
+    tab = synth.make_tables(tm, shard.ny_in, nx, args.seed, lat_range=(shard.in0, shard.in1, shard.ny_global))
+    x = hot.synth_field(tab, cell_base=shard.cell_base)  # [T, cells_in] resident in HBM before timing
+    own_rows = (shard.own0 - shard.in0, shard.own1 - shard.in0)
+    own = shard.own_cell_slice()
+
+    def step():
+        r = hot.shifting_hobday(
+            x, dcal, W=W, S=wl["S"], bins=bt, q=wl["pct"] / 100.0, wd=wl["wd"], ws=wl["ws"],
+            ny=shard.ny_in, nx=nx, own_rows=own_rows,
+        )
+        m = r["mask"][own].to(torch.int32)
+        inv = r["invalid_count"][own] * m
+        st = r["stats_dev"]
+        local = torch.stack([
+            m.sum().to(torch.int64), inv.sum().to(torch.int64), (inv > 0).sum().to(torch.int64),
+            r["n_true"][0], st[2].to(torch.int64), st[3].to(torch.int64),
+        ])
+        mx = inv.max().to(torch.int64).reshape(1)
+        if world > 1:
+            dist.all_reduce(local, op=dist.ReduceOp.SUM)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        return r, local, mx
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    hot.ctx.timing_enable(True)
+    hot.ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r, local, mx = step()
+    fence()
+    dt = time.perf_counter() - t0
+    hot.sync()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=hot.device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    kern = {k: hot.ctx.timing_get(k) for k in ("shifting", "thresholds", "mask", "transpose")}
+    summary = dict(zip(["n_ocean", "invalid_total", "invalid_cells", "n_extreme", "thr_too_low", "thr_too_high"],
+                       [int(v) for v in local.tolist()]))
+    summary["max_invalid"] = int(mx.item())
+
+    if rank == 0:
+        C_own_total = wl["ny"] * world * nx
+        units = T * C_own_total / 1e6  # Mcells*timesteps per step, whole job
+        ms_step = dt / args.steps * 1e3
+        value = units / (dt / args.steps)
+        T_out = cal.T_out
+        b_alg_rank = algorithmic_bytes(T, T_out, shard.cells_own)
+        # dominant kernel and its own algorithmic bytes
+        per_kernel_alg = {
+            "shifting": shard.cells_in * (4 * T + 4 * T_out + 1),
+            "thresholds": shard.cells_own * 4 * 366,
+            "mask": shard.cells_own * (4 * T_out + T_out + 4 * 366),
+            "transpose": shard.cells_in * 8 * 366,
+        }
+        dom = max(kern, key=lambda k: kern[k][0])
+        avg_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in kern.items()}
+        achieved = per_kernel_alg[dom] / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] else 0.0
+        out = {
+            "metric": "Mcells*timesteps/s, shifting_baseline + hobday_extreme p95 (validation+anomaly+thresholds+mask)",
+            "value": value,
+            "unit": "Mcells*timesteps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": wl["name"],
+                "per_gpu_grid": [wl["ny"], nx],
+                "global_grid": [wl["ny"] * world, nx],
+                "timesteps_in": T,
+                "timesteps_out": T_out,
+                "parallelism": f"lat-band x{world}, {halo} overlap rows, scalar all-reduce only",
+                "summary": summary,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": {"shifting": "k_shifting", "thresholds": "k_thresholds", "mask": "k_mask_ge", "transpose": "k_transpose"}[dom],
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_ms": avg_ms[dom],
+                "algorithmic_bytes_per_launch": per_kernel_alg[dom],
+            },
+            "pipeline_roofline": {
+                "algorithmic_bytes_per_step_per_gpu": b_alg_rank,
+                "achieved": b_alg_rank / (dt / args.steps) / 1e9,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": b_alg_rank / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+            },
+            "kernel_ms": avg_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, args.seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

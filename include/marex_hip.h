@@ -103,23 +103,27 @@ int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64
  *  centres[nb]        float32 bin centres, centres[0] == 0
  *  q, wd, ws          quantile in (0,1], odd day window (3..365), odd spatial window (1 = none)
  *  lower/upper_bound  edges[3] / edges[-2]
+ *  row0, row1         gridded only: thresholds are produced for grid rows row0 <= j < row1 (the rows a
+ *                     latitude shard owns; its overlap rows only feed the pooling).  Other rows of
+ *                     thr_doy_major are left untouched.  Pass 0, ny for everything.
  *  thr_doy_major      out [366, C]   (dayofyear-major working layout used by marex_mask_ge_doy_f32)
  *  stats              device struct, must be initialised {0xFFFFFFFF, 0, 0, 0} by the caller
  */
 int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins, int64_t T_out, int64_t C, int ny,
                                 int nx, const int32_t* doy_start, const float* first_anom,
                                 const float* centres, int nb, double q, int wd, int ws,
-                                float lower_bound, float upper_bound, float* thr_doy_major,
-                                marex_thr_stats* stats);
+                                float lower_bound, float upper_bound, int row0, int row1,
+                                float* thr_doy_major, marex_thr_stats* stats);
 
 /*
  * extreme[t, c] = anom[t, c] >= thr[doy(t), c]   (detect.py:2003-2004) and the count of True (833-835).
  *  doy_rows[T_out]   output rows sorted by (dayofyear, time); doy_start as above
+ *  c0, c1            only cells c0 <= c < c1 are compared, written and counted (owned cells of a shard)
  *  n_true            device counter, must be zeroed by the caller (may be NULL)
  */
 int marex_mask_ge_doy_f32(marex_ctx* ctx, const float* anom, const float* thr_doy_major,
                           const int32_t* doy_start, const int32_t* doy_rows, int64_t T_out, int64_t C,
-                          uint8_t* extreme, unsigned long long* n_true);
+                          int64_t c0, int64_t c1, uint8_t* extreme, unsigned long long* n_true);
 
 /* out[c, r] = in[r, c]  (thresholds [366, C] -> the reference's (cells, dayofyear) order) */
 int marex_transpose_f32(marex_ctx* ctx, const float* in, int64_t rows, int64_t cols, float* out);

@@ -40,9 +40,9 @@ PROTOTYPES = {
     ),
     "marex_hobday_thresholds_f32": (
         _i32,
-        [_p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i32, _f64, _i32, _i32, _f32, _f32, _p, _p],
+        [_p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i32, _f64, _i32, _i32, _f32, _f32, _i32, _i32, _p, _p],
     ),
-    "marex_mask_ge_doy_f32": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _p, _p]),
+    "marex_mask_ge_doy_f32": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "marex_transpose_f32": (_i32, [_p, _p, _i64, _i64, _p]),
 }
 
@@ -72,6 +72,10 @@ def load() -> C.CDLL:
             details=f"expected at {LIB_PATH}",
             suggestions=["run `python -m marex_amd.csrc.build` (needs hipcc, --offload-arch=gfx950)"],
         )
+    # torch owns the HBM buffers we are handed, so our kernels must launch through the SAME HIP runtime
+    # instance: import torch first so that libamdhip64 (same SONAME) is already mapped when we load.
+    import torch  # noqa: F401
+
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as exc:  # pragma: no cover - depends on the machine

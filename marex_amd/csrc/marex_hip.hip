@@ -59,14 +59,14 @@ struct LaunchTimer {
     hipEvent_t a = nullptr, b = nullptr;
     LaunchTimer(marex_ctx* c, int k) : ctx(c), kid(k) {
         if (ctx->timing) {
-            hipEventCreate(&a);
-            hipEventCreate(&b);
-            hipEventRecord(a, ctx->stream);
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, ctx->stream);
         }
     }
     ~LaunchTimer() {
         if (ctx->timing) {
-            hipEventRecord(b, ctx->stream);
+            (void)hipEventRecord(b, ctx->stream);
             ctx->pending.push_back({kid, a, b});
         }
     }
@@ -75,13 +75,13 @@ struct LaunchTimer {
 static void drain_timers(marex_ctx* ctx) {
     for (auto& p : ctx->pending) {
         float ms = 0.f;
-        hipEventSynchronize(p.b);
+        (void)hipEventSynchronize(p.b);
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             ctx->total_ms[p.kid] += ms;
             ctx->launches[p.kid] += 1;
         }
-        hipEventDestroy(p.a);
-        hipEventDestroy(p.b);
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
     }
     ctx->pending.clear();
 }
@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(256)
 k_thresholds(const unsigned short* __restrict__ bins, long C, int ny, int nx, int nseg_per_row, int NSEG,
              const int* __restrict__ doy_start, const float* __restrict__ first_anom,
              const float* __restrict__ centres, int nb, double q, int wd, int p, float lower_bound,
-             float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats) {
+             float upper_bound, int row0, float* __restrict__ thr, marex_thr_stats* __restrict__ stats) {
     extern __shared__ unsigned lds_u[];
     unsigned* hist = lds_u;                      // [NSEG][nb]
     int* st_iu = (int*)(hist + (size_t)NSEG * nb);  // [NSEG]
@@ -504,7 +504,7 @@ k_thresholds(const unsigned short* __restrict__ bins, long C, int ny, int nx, in
     int* st_tot = st_below + NSEG;               // [NSEG]
 
     const int tid = threadIdx.x;
-    const int j = (ny > 0) ? (int)(blockIdx.x / nseg_per_row) : 0;
+    const int j = (ny > 0) ? row0 + (int)(blockIdx.x / nseg_per_row) : 0;
     const int seg = (int)(blockIdx.x % nseg_per_row);
     const int i0 = seg * NSEG;
     const int nout = (nx - i0) < NSEG ? (nx - i0) : NSEG;
@@ -609,8 +609,8 @@ k_thresholds(const unsigned short* __restrict__ bins, long C, int ny, int nx, in
 extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins, int64_t T_out, int64_t C, int ny,
                                            int nx, const int32_t* doy_start, const float* first_anom,
                                            const float* centres, int nb, double q, int wd, int ws,
-                                           float lower_bound, float upper_bound, float* thr_doy_major,
-                                           marex_thr_stats* stats) {
+                                           float lower_bound, float upper_bound, int row0, int row1,
+                                           float* thr_doy_major, marex_thr_stats* stats) {
     if (!ctx) return -1;
     if (!bins || !doy_start || !first_anom || !centres || !thr_doy_major || !stats || T_out <= 0 || C <= 0)
         return fail(ctx, -1, "marex_hobday_thresholds_f32: null pointer or empty shape");
@@ -621,8 +621,12 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
     if (ny == 0) {
         if (ws > 1) return fail(ctx, -1, "marex_hobday_thresholds_f32: spatial pooling needs a structured grid");
         nx = (int)C;
+        row0 = 0;
+        row1 = 1;
     } else if ((int64_t)ny * nx != C) {
         return fail(ctx, -1, "marex_hobday_thresholds_f32: ny*nx != C");
+    } else if (row0 < 0 || row1 > ny || row0 >= row1) {
+        return fail(ctx, -1, "marex_hobday_thresholds_f32: need 0 <= row0 < row1 <= ny");
     }
     if (nb < 4 || nb > 36000) return fail(ctx, -4, "marex_hobday_thresholds_f32: nb must be in 4..36000");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -632,14 +636,14 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
     if (NSEG > nx) NSEG = nx;
     const size_t lds = (size_t)NSEG * (nb + 3) * 4;
     const int nseg_per_row = (nx + NSEG - 1) / NSEG;
-    const unsigned nblocks = (unsigned)nseg_per_row * (unsigned)(ny > 0 ? ny : 1);
+    const unsigned nblocks = (unsigned)nseg_per_row * (unsigned)(row1 - row0);
     if (lds > 48 * 1024)
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_thresholds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
         hipLaunchKernelGGL(k_thresholds, dim3(nblocks), dim3(256), lds, ctx->stream, bins, (long)C, ny, nx,
                            nseg_per_row, NSEG, doy_start, first_anom, centres, nb, q, wd, ws / 2, lower_bound,
-                           upper_bound, thr_doy_major, stats);
+                           upper_bound, row0, thr_doy_major, stats);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -653,13 +657,13 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
 template <int VEC>
 __global__ void __launch_bounds__(256)
 k_mask_ge(const float* __restrict__ anom, const float* __restrict__ thr, const int* __restrict__ doy_start,
-          const int* __restrict__ doy_rows, long C, unsigned char* __restrict__ out,
+          const int* __restrict__ doy_rows, long C, long c0, long c1, unsigned char* __restrict__ out,
           unsigned long long* __restrict__ n_true) {
     const int d = blockIdx.y;
-    const long c = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    const long c = c0 + ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
     const int r0 = doy_start[d], r1 = doy_start[d + 1];
     unsigned cnt = 0;
-    if (c < C) {
+    if (c < c1) {
         if (VEC == 4) {
             const float4 th = *reinterpret_cast<const float4*>(thr + (size_t)d * C + c);
 #pragma unroll 4
@@ -692,22 +696,24 @@ k_mask_ge(const float* __restrict__ anom, const float* __restrict__ thr, const i
 
 extern "C" int marex_mask_ge_doy_f32(marex_ctx* ctx, const float* anom, const float* thr_doy_major,
                                      const int32_t* doy_start, const int32_t* doy_rows, int64_t T_out, int64_t C,
-                                     uint8_t* extreme, unsigned long long* n_true) {
+                                     int64_t c0, int64_t c1, uint8_t* extreme, unsigned long long* n_true) {
     if (!ctx) return -1;
     if (!anom || !thr_doy_major || !doy_start || !doy_rows || !extreme || T_out <= 0 || C <= 0)
         return fail(ctx, -1, "marex_mask_ge_doy_f32: null pointer or empty shape");
+    if (c0 < 0 || c1 > C || c0 >= c1) return fail(ctx, -1, "marex_mask_ge_doy_f32: need 0 <= c0 < c1 <= C");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const bool vec = (C % 4 == 0) && (((uintptr_t)anom | (uintptr_t)thr_doy_major) % 16 == 0) && ((uintptr_t)extreme % 4 == 0);
+    const int64_t nc = c1 - c0;
+    const bool vec = (C % 4 == 0) && (c0 % 4 == 0) && (c1 % 4 == 0) && (((uintptr_t)anom | (uintptr_t)thr_doy_major) % 16 == 0) && ((uintptr_t)extreme % 4 == 0);
     {
         LaunchTimer lt(ctx, MAREX_K_MASK);
         if (vec) {
-            dim3 grid((unsigned)((C / 4 + 255) / 256), NDOY);
+            dim3 grid((unsigned)((nc / 4 + 255) / 256), NDOY);
             hipLaunchKernelGGL(k_mask_ge<4>, grid, dim3(256), 0, ctx->stream, anom, thr_doy_major, doy_start, doy_rows,
-                               (long)C, extreme, n_true);
+                               (long)C, (long)c0, (long)c1, extreme, n_true);
         } else {
-            dim3 grid((unsigned)((C + 255) / 256), NDOY);
+            dim3 grid((unsigned)((nc + 255) / 256), NDOY);
             hipLaunchKernelGGL(k_mask_ge<1>, grid, dim3(256), 0, ctx->stream, anom, thr_doy_major, doy_start, doy_rows,
-                               (long)C, extreme, n_true);
+                               (long)C, (long)c0, (long)c1, extreme, n_true);
         }
     }
     HIP_TRY(ctx, hipGetLastError());

@@ -1,0 +1,715 @@
+"""Drop-in host API of the hot path: ``preprocess_data`` and its public sub-functions.
+
+Same call signatures, option names, Dataset schema, attrs and error behaviour as the reference
+(marEx/detect.py:287-313, 891-907, 1119-1133, 1511-1517, 1691-1698); the numerics run on the MI355X
+through :class:`marex_amd.engine.HotPath` (HIP kernels behind the C ABI of include/marex_hip.h).
+There is no CPU fallback: without a HIP device the compute entry points raise.
+
+Deliberate differences:
+* in-memory (NumPy-backed) inputs are accepted -- the reference insists on Dask-backed arrays because it
+  builds a Dask graph (detect.py:558-568); Dask-backed xarray inputs are materialised with ``.values``;
+* ``dask_chunks`` / ``use_temp_checkpoints`` are accepted and ignored (identity on values);
+* ``window_days_hobday=1`` raises a ConfigurationError (it crashes the reference).
+"""
+
+from __future__ import annotations
+
+import logging
+import warnings
+from typing import Dict, List, Literal, Optional, Tuple
+
+import numpy as np
+
+from . import binning, calendar
+from .exceptions import ConfigurationError, DataValidationError, create_data_validation_error
+from .xr_compat import DataArray, Dataset, coord_values, to_numpy
+
+logger = logging.getLogger("marex_amd")
+
+_ANOMALY_METHODS = ["detrend_harmonic", "shifting_baseline", "fixed_baseline", "detrend_fixed_baseline"]
+_EXTREME_METHODS = ["global_extreme", "hobday_extreme"]
+
+_engine_cache: Dict[int, object] = {}
+
+
+def get_engine(device: int = 0):
+    """The per-device :class:`~marex_amd.engine.HotPath` (created on first use; raises without a GPU)."""
+    if device not in _engine_cache:
+        from .engine import HotPath
+
+        _engine_cache[device] = HotPath(device)
+    return _engine_cache[device]
+
+
+# ======================================================================================
+# validation helpers (detect.py:53-202)
+# ======================================================================================
+def _validate_dimensions_exist(da, dimensions: Dict[str, str]) -> None:
+    missing = [f"'{actual}' (for {concept})" for concept, actual in dimensions.items() if actual not in da.dims]
+    if missing:
+        available = list(da.dims)
+        raise create_data_validation_error(
+            f"Missing required dimensions: {', '.join(missing)}",
+            details=f"Dataset has dimensions: {available}",
+            suggestions=["Check dimension names in your data", "Update the 'dimensions' parameter to match your data structure"],
+            data_info={"missing_dimensions": missing, "available_dimensions": available, "provided_dimensions": dimensions},
+        )
+
+
+def _validate_coordinates_exist(da, coordinates: Dict[str, str]) -> None:
+    missing = [f"'{actual}' (for {concept})" for concept, actual in coordinates.items() if actual not in da.coords]
+    if missing:
+        available = list(da.coords.keys())
+        raise create_data_validation_error(
+            f"Missing required coordinates: {', '.join(missing)}",
+            details=f"Dataset has coordinates: {available}",
+            suggestions=["Check coordinate names in your data", "Update the 'coordinates' parameter to match your data structure"],
+            data_info={"missing_coordinates": missing, "available_coordinates": available, "provided_coordinates": coordinates},
+        )
+
+
+def _infer_dims_coords(da, dimensions: Optional[Dict[str, str]], coordinates: Optional[Dict[str, str]]):
+    """Defaults and existence checks of the dimension / coordinate name maps (detect.py:131-202)."""
+    if dimensions is None:
+        dimensions = {"time": "time", "x": "lon", "y": "lat"}
+    if "time" not in dimensions:
+        dimensions = {"time": "time", **dimensions}
+    if coordinates is None:
+        if "y" not in dimensions:
+            raise create_data_validation_error(
+                "Coordinates parameter must be explicitly specified for unstructured data",
+                details="Unstructured data requires coordinate names for x and y spatial coordinates",
+                suggestions=["Example: coordinates={'time': 'time', 'x': 'lon', 'y': 'lat'}"],
+                data_info={"data_structure": "unstructured (2D)", "dimensions": dimensions},
+            )
+        coordinates = dimensions.copy()
+    elif "time" not in coordinates:
+        coordinates = {"time": dimensions.get("time", "time"), **coordinates}
+    _validate_dimensions_exist(da, dimensions)
+    _validate_coordinates_exist(da, coordinates)
+    return dimensions, coordinates
+
+
+def _get_preprocessing_steps(
+    method_anomaly: str,
+    method_extreme: str,
+    std_normalise: bool,
+    detrend_orders: List[int],
+    window_year_baseline: int,
+    smooth_days_baseline: int,
+    window_days_hobday: int,
+    window_spatial_hobday: Optional[int],
+    reference_period: Optional[Tuple[int, int]] = None,
+) -> List[str]:
+    """Provenance strings stored in ``attrs['preprocessing_steps']`` (detect.py:844-888; golden-pinned)."""
+    steps: List[str] = []
+    ref = f"{reference_period[0]}-{reference_period[1]}" if reference_period is not None else None
+    if method_anomaly == "detrend_harmonic":
+        steps.append(f"Removed polynomial trend orders={detrend_orders} & seasonal cycle")
+        if std_normalise:
+            steps.append("Normalised by 30-day rolling STD")
+    elif method_anomaly == "shifting_baseline":
+        steps += [f"Rolling climatology using {window_year_baseline} years", f"Smoothed with {smooth_days_baseline}-day window"]
+    elif method_anomaly == "fixed_baseline":
+        steps.append(f"Daily climatology computed from {ref}" if ref else "Daily climatology computed from full time series")
+    elif method_anomaly == "detrend_fixed_baseline":
+        steps.append(f"Removed polynomial trend orders={detrend_orders}")
+        steps.append(
+            f"Daily climatology computed from detrended data ({ref})" if ref else "Daily climatology computed from detrended data"
+        )
+    if method_extreme == "global_extreme":
+        steps.append("Global percentile threshold applied to all days")
+    elif method_extreme == "hobday_extreme":
+        txt = f"Day-of-year thresholds with {window_days_hobday} day window"
+        if window_spatial_hobday is not None:
+            txt += f" & {window_spatial_hobday} spatial neighbours"
+        steps.append(txt)
+    return steps
+
+
+# ======================================================================================
+# array <-> labelled-array plumbing
+# ======================================================================================
+class _Field:
+    """A DataArray flattened to the device layout ``[T, C]`` plus what is needed to rebuild labelled outputs."""
+
+    def __init__(self, da, dimensions: Dict[str, str], coordinates: Dict[str, str]):
+        self.dimensions, self.coordinates = dimensions, coordinates
+        self.tdim = dimensions["time"]
+        self.gridded = "y" in dimensions
+        self.sdims = [dimensions["y"], dimensions["x"]] if self.gridded else [dimensions["x"]]
+        extra = [d for d in da.dims if d != self.tdim and d not in self.sdims]
+        if extra:
+            raise create_data_validation_error(
+                f"Unsupported extra dimensions {extra}", details="expected (time, y, x) or (time, cells) data"
+            )
+        self.da = da
+        arr = to_numpy(da.transpose(self.tdim, *self.sdims))
+        self.sshape = tuple(arr.shape[1:])
+        self.ny, self.nx = (self.sshape if self.gridded else (0, self.sshape[0]))
+        self.x = np.ascontiguousarray(arr.reshape(arr.shape[0], -1), dtype=np.float32)  # cast as detect.py:600
+        self.time = coord_values(da, coordinates["time"])
+        self.scoords = {}
+        for d in self.sdims:
+            if d in da.coords:
+                self.scoords[d] = da.coords[d]
+        for key in ("x", "y"):
+            name = coordinates.get(key)
+            if name is not None and name in da.coords and name not in self.scoords:
+                self.scoords[name] = da.coords[name]
+
+    def labelled(self, data: np.ndarray, lead: Optional[Tuple[str, np.ndarray]], trail: Optional[Tuple[str, np.ndarray]] = None):
+        """Wrap ``data`` with dims ``(lead?, *spatial, trail?)``; ``data``'s cell axis is still flat."""
+        dims, coords, shape = [], {}, []
+        if lead is not None:
+            dims.append(lead[0]); coords[lead[0]] = lead[1]; shape.append(len(lead[1]))
+        dims += self.sdims
+        shape += list(self.sshape)
+        if trail is not None:
+            dims.append(trail[0]); coords[trail[0]] = trail[1]; shape.append(len(trail[1]))
+        coords.update(self.scoords)
+        return DataArray(np.asarray(data).reshape(shape), dims=dims, coords=coords)
+
+
+def _raise_if_invalid(field: _Field, summary: Dict[str, int]) -> None:
+    """Error texts of ``_validate_data_values`` (detect.py:224-279) from the device-side counts."""
+    T, C = field.x.shape
+    if summary["n_ocean"] == 0:
+        raise create_data_validation_error(
+            "Dataset contains no valid (finite) data",
+            details="All values in the first time step are NaN or infinite",
+            suggestions=["Check your input data for data quality issues", "Verify the data was loaded correctly"],
+            data_info={"total_values": int(T * C), "total_spatial_locations": int(C)},
+        )
+    if summary["max_invalid"] > 0:
+        raise create_data_validation_error(
+            f"Dataset contains {summary['invalid_total']} invalid values in {summary['invalid_cells']} ocean locations",
+            details=(
+                f"Found invalid data across time series. Worst location has {summary['max_invalid']} "
+                f"invalid time steps out of {T}."
+            ),
+            suggestions=[
+                "Remove or interpolate NaN/infinite values before preprocessing",
+                "For ocean data, ensure land mask is properly applied before preprocessing",
+            ],
+            data_info={
+                "total_invalid_values_in_ocean": summary["invalid_total"],
+                "locations_affected": summary["invalid_cells"],
+                "total_ocean_locations": summary["n_ocean"],
+                "max_invalid_at_one_location": summary["max_invalid"],
+                "total_time_steps": int(T),
+            },
+        )
+
+
+def _check_reference_period_allowed(reference_period, method_anomaly: str) -> None:
+    if reference_period is not None and method_anomaly not in ("fixed_baseline", "detrend_fixed_baseline"):
+        raise ConfigurationError(
+            f"reference_period is not supported for method_anomaly='{method_anomaly}'",
+            details="reference_period is only applicable to 'fixed_baseline' and 'detrend_fixed_baseline' methods",
+            suggestions=["Remove the reference_period parameter, or", "Use method_anomaly='fixed_baseline' or 'detrend_fixed_baseline'"],
+        )
+
+
+def _check_detrend_orders(detrend_orders) -> None:
+    """detect.py:2104-2126."""
+    if not detrend_orders:
+        raise ConfigurationError(
+            "detrend_orders cannot be empty",
+            details="At least one polynomial order must be specified for detrending",
+            suggestions=["Use detrend_orders=[1] for linear detrending"],
+        )
+    bad = [o for o in detrend_orders if o < 1]
+    if bad:
+        raise ConfigurationError(
+            f"Invalid polynomial orders: {bad}",
+            details="Polynomial orders must be positive integers (≥ 1)",
+            suggestions=["Use only positive integers for polynomial orders"],
+        )
+
+
+def _check_reference_period_values(reference_period, years: np.ndarray) -> None:
+    """detect.py:2334-2355."""
+    if reference_period is None:
+        return
+    a, b = reference_period
+    if a > b:
+        raise ConfigurationError(
+            f"Invalid reference_period: start year ({a}) must be <= end year ({b})",
+            details="The reference_period tuple must be (start_year, end_year) with start_year <= end_year",
+            suggestions=[f"Swap the order: use reference_period=({b}, {a})"],
+        )
+    if not ((years >= a) & (years <= b)).any():
+        lo, hi = int(years.min()), int(years.max())
+        raise ConfigurationError(
+            f"No data found in reference_period ({a}, {b})",
+            details=f"Dataset spans {lo}-{hi} but no timesteps fall within the specified period",
+            suggestions=[f"Adjust reference_period to overlap with data range ({lo}-{hi})", "Set reference_period=None to use the full time series"],
+        )
+
+
+def _validate_extreme_options(
+    gridded: bool, method_extreme, threshold_percentile, window_days_hobday, window_spatial_hobday,
+    method_percentile, precision, max_anomaly,
+) -> Optional[int]:
+    """Option checks of ``identify_extremes`` in the reference's order (detect.py:1277-1470).
+
+    Returns the effective spatial window (5 on gridded data when ``None`` and hobday, detect.py:1451-1452).
+    """
+    if method_percentile not in ("exact", "approximate"):
+        raise ConfigurationError(
+            f"Unknown method_percentile '{method_percentile}'",
+            details="Invalid method_percentile parameter",
+            suggestions=["Use 'exact' for precise percentile computation (memory intensive)",
+                         "Use 'approximate' for efficient histogram-based computation (default)"],
+            context={"provided_method": method_percentile, "valid_methods": ["exact", "approximate"]},
+        )
+    if method_percentile == "exact":
+        for pname, val, dflt in (("precision", precision, 0.01), ("max_anomaly", max_anomaly, 5.0)):
+            if val != dflt:
+                raise ConfigurationError(
+                    f"Parameter '{pname}' cannot be used with method_percentile='exact'",
+                    details=f"The {pname} parameter ({pname}={val}) is only used by the approximate histogram method",
+                    suggestions=[f"Remove the '{pname}' parameter when using method_percentile='exact'"],
+                    context={"method_percentile": method_percentile, f"provided_{pname}": val, f"default_{pname}": dflt},
+                )
+    if threshold_percentile < 60 and method_percentile == "approximate":
+        raise ConfigurationError(
+            f"Percentile threshold {threshold_percentile}% is not supported with method_percentile='approximate'",
+            details="Low percentile thresholds (<60%) produce undefined and unsupported behaviour when using approximate histogram methods",
+            suggestions=["Use method_percentile='exact' for percentiles below 60%"],
+            context={"threshold_percentile": threshold_percentile, "method_percentile": method_percentile, "min_supported_percentile": 60},
+        )
+    if window_spatial_hobday is not None:
+        if not gridded:
+            raise ConfigurationError(
+                "window_spatial_hobday is not supported for unstructured grids",
+                details="Spatial smoothing with window_spatial_hobday requires structured grids with both x and y dimensions.",
+                suggestions=["Remove the window_spatial_hobday parameter for unstructured grids"],
+                context={"grid_type": "unstructured", "window_spatial_hobday": window_spatial_hobday},
+            )
+        if method_extreme != "hobday_extreme":
+            raise ConfigurationError(
+                "window_spatial_hobday can only be used with method_extreme='hobday_extreme'",
+                details="The window_spatial_hobday parameter is only implemented for the Hobday extreme method.",
+                suggestions=["Remove the window_spatial_hobday parameter when using method_extreme='global_extreme'"],
+                context={"method_extreme": method_extreme, "window_spatial_hobday": window_spatial_hobday},
+            )
+        if method_percentile == "exact":
+            raise ConfigurationError(
+                "window_spatial_hobday is not supported with method_percentile='exact'",
+                details="The window_spatial_hobday parameter is only implemented for the approximate percentile method.",
+                suggestions=["Remove the window_spatial_hobday parameter when using method_percentile='exact'"],
+                context={"method_percentile": method_percentile, "window_spatial_hobday": window_spatial_hobday},
+            )
+    if method_extreme == "hobday_extreme" and window_days_hobday is not None and window_days_hobday % 2 == 0:
+        raise ConfigurationError(
+            "window_days_hobday must be an odd number",
+            details=f"window_days_hobday={window_days_hobday} is even, which would create asymmetric temporal windows.",
+            suggestions=[f"Use window_days_hobday={window_days_hobday + 1} or {window_days_hobday - 1}"],
+            context={"window_days_hobday": window_days_hobday, "is_odd": False},
+        )
+    ws_eff = window_spatial_hobday
+    if method_extreme == "hobday_extreme" and ws_eff is None and gridded and method_percentile == "approximate":
+        ws_eff = 5
+    if method_extreme == "hobday_extreme" and window_spatial_hobday is None and gridded and method_percentile == "exact":
+        ws_eff = None  # the default 5 is set (detect.py:1452) but the exact branch never pools
+    if method_extreme == "hobday_extreme" and ws_eff is not None and ws_eff % 2 == 0:
+        raise ConfigurationError(
+            "window_spatial_hobday must be an odd number",
+            details=f"window_spatial_hobday={ws_eff} is even, which would create asymmetric spatial windows.",
+            suggestions=["Choose an odd number."],
+            context={"window_spatial_hobday": ws_eff, "is_odd": False},
+        )
+    if method_extreme not in _EXTREME_METHODS:
+        raise ConfigurationError(
+            f"Unknown extreme method '{method_extreme}'",
+            details="Invalid method_extreme parameter",
+            suggestions=["Use 'global_extreme' for efficient constant percentile threshold",
+                         "Use 'hobday_extreme' for day-of-year specific thresholds"],
+            context={"provided_method": method_extreme, "valid_methods": _EXTREME_METHODS},
+        )
+    if method_extreme == "hobday_extreme" and method_percentile == "approximate" and window_days_hobday < 3:
+        raise ConfigurationError(
+            "window_days_hobday must be at least 3 with method_percentile='approximate'",
+            details="a 1-day window makes the reference's wrap padding degenerate (it raises a broadcast ValueError there)",
+            suggestions=["Use window_days_hobday >= 3"],
+        )
+    return ws_eff
+
+
+# ======================================================================================
+# core on flat arrays (device)
+# ======================================================================================
+def _anomaly_core(eng, field: _Field, method_anomaly, window_year_baseline, smooth_days_baseline, detrend_orders,
+                  force_zero_mean, reference_period, want_bins: Optional[binning.BinTable]):
+    """Runs the anomaly stage on the device.  Returns dict with device tensors + the calendar plan."""
+    import torch
+
+    x = torch.from_numpy(field.x).to(eng.device)
+    if method_anomaly == "shifting_baseline":
+        cal = calendar.build_calendar(field.time, window_year_baseline=int(window_year_baseline))
+        total_years = cal.n_cal_years
+        if total_years < window_year_baseline:  # detect.py:622-636
+            raise create_data_validation_error(
+                "Insufficient data for shifting_baseline method",
+                details=f"Dataset spans {total_years} years but requires at least {window_year_baseline} years",
+                suggestions=["Use more years of data to meet minimum requirement",
+                             f"Reduce window_year_baseline parameter (currently {window_year_baseline})"],
+                data_info={"available_years": int(total_years), "required_years": int(window_year_baseline)},
+            )
+        if cal.T_out == 0:
+            raise create_data_validation_error(
+                "Insufficient data for shifting_baseline method",
+                details=f"no timestep is left after removing the first {window_year_baseline} years",
+            )
+        dcal = eng.upload_calendar(cal)
+        r = eng.shifting_baseline(x, dcal, int(window_year_baseline), int(smooth_days_baseline), want_bins)
+        return {"anom": r["out"], "mask": r["mask"], "invalid": r["invalid_count"], "bins": r.get("bins"), "cal": cal, "dcal": dcal}
+    cal = calendar.build_calendar(field.time)
+    dcal = eng.upload_calendar(cal)
+    if method_anomaly == "fixed_baseline":
+        _check_reference_period_values(reference_period, cal.year)
+        r = eng.fixed_baseline(x, dcal, reference_period, want_bins, count_invalid=True)
+    elif method_anomaly in ("detrend_harmonic", "detrend_fixed_baseline"):
+        _check_detrend_orders(detrend_orders)
+        if 1 not in detrend_orders and len(detrend_orders) > 1:
+            print("Warning: Higher-order detrending without linear term may be unstable")  # detect.py:2135-2136
+        harm = method_anomaly == "detrend_harmonic"
+        model, pmodel = calendar.detrend_model(calendar.decimal_year(field.time), detrend_orders, harm)
+        if method_anomaly == "detrend_fixed_baseline":
+            _check_reference_period_values(reference_period, cal.year)
+            d = eng.detrend(x, model, pmodel, bool(force_zero_mean), None, count_invalid=True)
+            r = eng.fixed_baseline(d["out"], dcal, reference_period, want_bins, count_invalid=False)
+            r["mask"], r["invalid_count"] = d["mask"], d["invalid_count"]
+        else:
+            r = eng.detrend(x, model, pmodel, bool(force_zero_mean), (want_bins, dcal), count_invalid=True)
+    else:
+        raise ConfigurationError(
+            f"Unknown anomaly method '{method_anomaly}'",
+            details="Invalid method_anomaly parameter",
+            suggestions=["Use 'detrend_harmonic' for efficient processing with trend and harmonic removal",
+                         "Use 'shifting_baseline' for accurate climatology (requires more data)",
+                         "Use 'fixed_baseline' to remove a single daily climatology across all years",
+                         "Use 'detrend_fixed_baseline' for trend removal followed by fixed climatology"],
+            context={"provided_method": method_anomaly, "valid_methods": _ANOMALY_METHODS},
+        )
+    return {"anom": r["out"], "mask": r["mask"], "invalid": r["invalid_count"], "bins": r.get("bins"), "cal": cal, "dcal": dcal}
+
+
+def _validation_summary(a) -> Dict[str, int]:
+    import torch
+
+    m = a["mask"].to(torch.int32)
+    inv = a["invalid"] * m
+    return {
+        "n_ocean": int(m.sum().item()),
+        "invalid_total": int(inv.sum().item()),
+        "invalid_cells": int((inv > 0).sum().item()),
+        "max_invalid": int(inv.max().item()) if inv.numel() else 0,
+    }
+
+
+def _warn_threshold_range(stats: Dict[str, float], bt: binning.BinTable, max_anomaly: float) -> None:
+    """The two UserWarnings of detect.py:2711-2730."""
+    if stats["n_too_high"] > 0:
+        warnings.warn(
+            f"Quantile values exceed expected range: max={stats['max']:.4f} > {bt.upper_bound:.4f}. "
+            f"Consider increasing max_anomaly parameter (currently {max_anomaly:.2f}) or using a lower percentile threshold.",
+            UserWarning, stacklevel=3,
+        )
+    if stats["n_too_low"] > 0:
+        warnings.warn(
+            f"Quantile values below expected range in some locations: min={stats['min']:.4f} < {bt.lower_bound:.4f}. "
+            "This is likely due to a constant anomaly in certain (e.g. due to sea ice). "
+            "Double check the computed threshold values are correct.",
+            UserWarning, stacklevel=3,
+        )
+
+
+def _extremes_core(eng, a, field: _Field, method_extreme, threshold_percentile, window_days_hobday, ws_eff,
+                   method_percentile, bt: Optional[binning.BinTable], max_anomaly):
+    """Threshold + mask stage on the device.  Returns (extreme uint8 [T', C], thresholds (host layout), dims tag)."""
+    cal, dcal = a["cal"], a["dcal"]
+    if method_extreme == "hobday_extreme":
+        n_years = cal.n_years_present if cal.T_out == cal.T else int(np.unique(cal.year[cal.kept]).size)
+        n_above = n_years * window_days_hobday * (ws_eff if ws_eff is not None else 1) ** 2 * (1.0 - threshold_percentile / 100.0)
+        if n_above < 50:  # detect.py:1905-1915
+            logger.warning(
+                f"Not enough samples for accurate extreme detection: {n_above} < 50. "
+                "Consider using a lower threshold_percentile, increasing your time-series size, "
+                "increasing the window_days_hobday, or using a larger window_spatial_hobday."
+            )
+        if method_percentile == "exact":
+            thr_doy = eng.hobday_thresholds_exact(a["anom"], dcal, float(threshold_percentile), int(window_days_hobday))
+            m = eng.mask_ge_doy(a["anom"], thr_doy, dcal)
+            return m["extreme"], thr_doy, "doy_first", m["n_true"]
+        t = eng.hobday_thresholds(
+            a["bins"], a["anom"], dcal, bt, threshold_percentile / 100.0, int(window_days_hobday),
+            int(ws_eff) if ws_eff else 1, field.ny, field.nx,
+        )
+        m = eng.mask_ge_doy(a["anom"], t["thr_doy_major"], dcal)
+        thr = eng.transpose(t["thr_doy_major"])
+        _warn_threshold_range(eng.decode_thr_stats(t["stats_dev"]), bt, max_anomaly)
+        return m["extreme"], thr, "doy_last", m["n_true"]
+    # global_extreme
+    g = eng.global_threshold(a["anom"], float(threshold_percentile), method_percentile, bt)
+    if method_percentile == "approximate":
+        _warn_threshold_range(g["stats"], binning.global_bins(bt.precision, bt.max_anomaly), max_anomaly)
+    m = eng.mask_ge_const(a["anom"], g["thr_f64"])
+    return m["extreme"], g["thr_f64"], "none", m["n_true"]
+
+
+# ======================================================================================
+# public API
+# ======================================================================================
+def preprocess_data(
+    da,
+    method_anomaly: Literal["detrend_harmonic", "shifting_baseline", "fixed_baseline", "detrend_fixed_baseline"] = "shifting_baseline",
+    method_extreme: Literal["global_extreme", "hobday_extreme"] = "hobday_extreme",
+    threshold_percentile: float = 95,
+    window_year_baseline: int = 15,
+    smooth_days_baseline: int = 21,
+    window_days_hobday: int = 11,
+    window_spatial_hobday: Optional[int] = None,
+    std_normalise: bool = False,
+    detrend_orders: Optional[List[int]] = None,
+    force_zero_mean: bool = True,
+    reference_period: Optional[Tuple[int, int]] = None,
+    method_percentile: Literal["exact", "approximate"] = "approximate",
+    precision: float = 0.01,
+    max_anomaly: float = 5.0,
+    dask_chunks: Optional[Dict[str, int]] = None,
+    dimensions: Optional[Dict[str, str]] = None,
+    coordinates: Optional[Dict[str, str]] = None,
+    neighbours=None,
+    cell_areas=None,
+    use_temp_checkpoints: bool = False,
+    verbose: Optional[bool] = None,
+    quiet: Optional[bool] = None,
+    device: int = 0,
+):
+    """Anomalies, thresholds and the boolean extreme mask of a (time, [lat,] lon / cells) field.
+
+    Mirror of ``marEx.preprocess_data`` (detect.py:287-841).  Returns a Dataset with ``dat_anomaly``
+    (float32), ``mask`` (bool), ``extreme_events`` (bool), ``thresholds`` (float32, dims
+    ``(*space, dayofyear)`` for the approximate Hobday method, ``(dayofyear, *space)`` for the exact one,
+    ``(*space)`` float64 for ``global_extreme``) and the reference's attrs.
+    """
+    if detrend_orders is None:
+        detrend_orders = [1]
+    if dask_chunks is None:
+        dask_chunks = {"time": 25}
+    if verbose:
+        logger.setLevel(logging.DEBUG)
+    elif quiet:
+        logger.setLevel(logging.WARNING)
+    logger.info(f"Starting data preprocessing - Method: {method_anomaly} -> {method_extreme}")
+
+    dimensions, coordinates = _infer_dims_coords(da, dimensions, coordinates)
+    _check_reference_period_allowed(reference_period, method_anomaly)
+    if std_normalise and method_anomaly == "detrend_harmonic":
+        raise ConfigurationError(
+            "std_normalise=True is not available on the device path yet",
+            details="the 30-day rolling STD normalisation (detect.py:2257-2293) is listed as a next step (SURVEY.md 8f)",
+        )
+    if method_anomaly not in _ANOMALY_METHODS:
+        raise ConfigurationError(
+            f"Unknown anomaly method '{method_anomaly}'",
+            details="Invalid method_anomaly parameter",
+            suggestions=["Use 'detrend_harmonic', 'shifting_baseline', 'fixed_baseline' or 'detrend_fixed_baseline'"],
+            context={"provided_method": method_anomaly, "valid_methods": _ANOMALY_METHODS},
+        )
+    gridded = "y" in dimensions
+    ws_eff = _validate_extreme_options(
+        gridded, method_extreme, threshold_percentile, window_days_hobday, window_spatial_hobday,
+        method_percentile, precision, max_anomaly,
+    )
+
+    field = _Field(da, dimensions, coordinates)
+    eng = get_engine(device)
+    bt = binning.hobday_bins(precision, max_anomaly) if method_percentile == "approximate" else None
+    need_bins = bt if (method_extreme == "hobday_extreme" and method_percentile == "approximate") else None
+
+    a = _anomaly_core(eng, field, method_anomaly, window_year_baseline, smooth_days_baseline, detrend_orders,
+                      force_zero_mean, reference_period, need_bins)
+    _raise_if_invalid(field, _validation_summary(a))
+    cal = a["cal"]
+    if method_anomaly == "shifting_baseline":
+        logger.info(f"Trimming data to start from {cal.min_year + window_year_baseline} (removing first {window_year_baseline} years)")
+
+    ext, thr, thr_kind, n_true = _extremes_core(
+        eng, a, field, method_extreme, threshold_percentile, window_days_hobday, ws_eff, method_percentile, bt, max_anomaly
+    )
+    eng.sync()
+
+    time_out = field.time[cal.kept]
+    tlead = (field.tdim, time_out)
+    ds = Dataset()
+    ds["dat_anomaly"] = field.labelled(a["anom"].cpu().numpy(), tlead)
+    ds["mask"] = field.labelled(a["mask"].cpu().numpy().astype(bool), None)
+    ds["extreme_events"] = field.labelled(ext.cpu().numpy().astype(bool), tlead)
+    doy_axis = ("dayofyear", np.arange(1, calendar.N_DOY + 1))
+    thr_np = thr.cpu().numpy()
+    if thr_kind == "doy_last":
+        ds["thresholds"] = field.labelled(thr_np, None, doy_axis)
+    elif thr_kind == "doy_first":
+        ds["thresholds"] = field.labelled(thr_np, doy_axis)
+    else:
+        ds["thresholds"] = field.labelled(thr_np, None)
+    if neighbours is not None:
+        ds["neighbours"] = neighbours.astype(np.int32)
+    if cell_areas is not None:
+        ds["cell_areas"] = cell_areas.astype(np.float32)
+
+    # attrs exactly as detect.py:731-783
+    ds.attrs.update({
+        "method_anomaly": method_anomaly,
+        "method_extreme": method_extreme,
+        "threshold_percentile": threshold_percentile,
+        "preprocessing_steps": _get_preprocessing_steps(
+            method_anomaly, method_extreme, std_normalise, detrend_orders, window_year_baseline,
+            smooth_days_baseline, window_days_hobday, window_spatial_hobday, reference_period,
+        ),
+    })
+    if method_anomaly == "detrend_harmonic":
+        ds.attrs.update({"detrend_orders": detrend_orders, "force_zero_mean": force_zero_mean, "std_normalise": std_normalise})
+    elif method_anomaly == "shifting_baseline":
+        ds.attrs.update({"window_year_baseline": window_year_baseline, "smooth_days_baseline": smooth_days_baseline})
+    elif method_anomaly == "fixed_baseline":
+        if reference_period is not None:
+            ds.attrs["reference_period"] = list(reference_period)
+    elif method_anomaly == "detrend_fixed_baseline":
+        ds.attrs.update({"detrend_orders": detrend_orders, "force_zero_mean": force_zero_mean})
+        if reference_period is not None:
+            ds.attrs["reference_period"] = list(reference_period)
+    if method_extreme == "hobday_extreme":
+        ds.attrs["window_days_hobday"] = window_days_hobday
+    ds.attrs.update({"method_percentile": method_percentile, "precision": precision, "max_anomaly": max_anomaly})
+    logger.info(f"Preprocessing completed successfully - {int(n_true.item())} extreme events identified")
+    return ds
+
+
+def compute_normalised_anomaly(
+    da,
+    method_anomaly: str = "shifting_baseline",
+    dimensions: Optional[Dict[str, str]] = None,
+    coordinates: Optional[Dict[str, str]] = None,
+    window_year_baseline: int = 15,
+    smooth_days_baseline: int = 21,
+    std_normalise: bool = False,
+    detrend_orders: Optional[List[int]] = None,
+    force_zero_mean: bool = True,
+    reference_period: Optional[Tuple[int, int]] = None,
+    use_temp_checkpoints: bool = False,
+    verbose: Optional[bool] = None,
+    quiet: Optional[bool] = None,
+    device: int = 0,
+):
+    """Anomaly stage only (detect.py:891-1116).  Returns ``Dataset{dat_anomaly, mask}`` over ALL timesteps.
+
+    For ``shifting_baseline`` the first ``window_year_baseline`` years are NaN (no climatology), as in the
+    reference where the trim happens later in ``preprocess_data``.
+    """
+    if detrend_orders is None:
+        detrend_orders = [1]
+    dimensions, coordinates = _infer_dims_coords(da, dimensions, coordinates)
+    _check_reference_period_allowed(reference_period, method_anomaly)
+    if method_anomaly not in _ANOMALY_METHODS:
+        raise ConfigurationError(
+            f"Unknown anomaly method '{method_anomaly}'",
+            details="Invalid method_anomaly parameter",
+            context={"provided_method": method_anomaly, "valid_methods": _ANOMALY_METHODS},
+        )
+    field = _Field(da, dimensions, coordinates)
+    eng = get_engine(device)
+    a = _anomaly_core(eng, field, method_anomaly, window_year_baseline, smooth_days_baseline, detrend_orders,
+                      force_zero_mean, reference_period, None)
+    eng.sync()
+    cal = a["cal"]
+    anom = a["anom"].cpu().numpy()
+    if method_anomaly == "shifting_baseline":
+        full = np.full(field.x.shape, np.nan, dtype=np.float32)
+        full[cal.kept] = anom
+        anom = full
+    ds = Dataset()
+    ds["dat_anomaly"] = field.labelled(anom, (field.tdim, field.time))
+    ds["mask"] = field.labelled(a["mask"].cpu().numpy().astype(bool), None)
+    return ds
+
+
+def identify_extremes(
+    da,
+    method_extreme: str = "hobday_extreme",
+    threshold_percentile: float = 95,
+    dimensions: Optional[Dict[str, str]] = None,
+    coordinates: Optional[Dict[str, str]] = None,
+    window_days_hobday: int = 11,
+    window_spatial_hobday: Optional[int] = None,
+    method_percentile: str = "approximate",
+    precision: float = 0.01,
+    max_anomaly: float = 5.0,
+    use_temp_checkpoints: bool = False,
+    verbose: Optional[bool] = None,
+    quiet: Optional[bool] = None,
+    device: int = 0,
+):
+    """Threshold + mask stage on given anomalies (detect.py:1119-1503).  Returns ``(extremes, thresholds)``."""
+    import torch
+
+    dimensions, coordinates = _infer_dims_coords(da, dimensions, coordinates)
+    gridded = "y" in dimensions and dimensions["y"] in da.dims
+    ws_eff = _validate_extreme_options(
+        gridded, method_extreme, threshold_percentile, window_days_hobday, window_spatial_hobday,
+        method_percentile, precision, max_anomaly,
+    )
+    field = _Field(da, dimensions, coordinates)
+    eng = get_engine(device)
+    bt = binning.hobday_bins(precision, max_anomaly) if method_percentile == "approximate" else None
+    cal = calendar.build_calendar(field.time)
+    dcal = eng.upload_calendar(cal)
+    anom = torch.from_numpy(field.x).to(eng.device)
+    a = {"anom": anom, "cal": cal, "dcal": dcal, "bins": None}
+    if method_extreme == "hobday_extreme" and method_percentile == "approximate":
+        a["bins"] = eng.digitize(anom, dcal, bt)
+    ext, thr, kind, _ = _extremes_core(
+        eng, a, field, method_extreme, threshold_percentile, window_days_hobday, ws_eff, method_percentile, bt, max_anomaly
+    )
+    eng.sync()
+    extremes = field.labelled(ext.cpu().numpy().astype(bool), (field.tdim, field.time))
+    doy_axis = ("dayofyear", np.arange(1, calendar.N_DOY + 1))
+    if kind == "doy_last":
+        thresholds = field.labelled(thr.cpu().numpy(), None, doy_axis)
+    elif kind == "doy_first":
+        thresholds = field.labelled(thr.cpu().numpy(), doy_axis)
+    else:
+        thresholds = field.labelled(thr.cpu().numpy(), None)
+    return extremes, thresholds
+
+
+def _climatology(da, window_year_baseline, smooth_days, dimensions, coordinates, device):
+    dimensions, coordinates = _infer_dims_coords(da, dimensions, coordinates)
+    field = _Field(da, dimensions, coordinates)
+    eng = get_engine(device)
+    import torch
+
+    cal_trim = calendar.build_calendar(field.time, window_year_baseline=int(window_year_baseline))
+    dcal = eng.upload_calendar(cal_trim)
+    x = torch.from_numpy(field.x).to(eng.device)
+    r = eng.shifting_baseline(x, dcal, int(window_year_baseline), int(smooth_days), None, write_clim=True)
+    eng.sync()
+    full = np.full(field.x.shape, np.nan, dtype=np.float32)
+    full[cal_trim.kept] = r["out"].cpu().numpy()
+    return field.labelled(full, (field.tdim, field.time))
+
+
+def rolling_climatology(da, window_year_baseline: int = 15, dimensions=None, coordinates=None,
+                        use_temp_checkpoints: bool = False, device: int = 0):
+    """Day-of-year climatology of the previous ``window_year_baseline`` years for every timestep (detect.py:1511-1688)."""
+    return _climatology(da, window_year_baseline, 1, dimensions, coordinates, device)
+
+
+def smoothed_rolling_climatology(da, window_year_baseline: int = 15, smooth_days_baseline: int = 21, dimensions=None,
+                                 coordinates=None, use_temp_checkpoints: bool = False, device: int = 0):
+    """``rolling_climatology`` of the centred ``smooth_days_baseline`` rolling mean (detect.py:1691-1816)."""
+    return _climatology(da, window_year_baseline, smooth_days_baseline, dimensions, coordinates, device)

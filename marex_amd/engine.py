@@ -48,6 +48,7 @@ class HotPath:
         self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
         self.ctx = _lib.Context(self.device.index)
         self.lib = self.ctx.lib
+        self._tables: Dict[int, tuple] = {}
         self._bind_stream()
 
     # ------------------------------------------------------------------ plumbing
@@ -70,6 +71,13 @@ class HotPath:
 
     def sync(self) -> None:
         self.ctx.sync()
+
+    def bin_tables(self, bins: BinTable):
+        """(edges, centres) of a bin table on the device, uploaded once per table object."""
+        key = id(bins)
+        if key not in self._tables:
+            self._tables[key] = (self._dev(bins.edges, np.float32), self._dev(bins.centres, np.float32), bins)
+        return self._tables[key][:2]
 
     # ------------------------------------------------------------------ synthetic field
     def synth_field(self, tab, cell_base: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -117,7 +125,7 @@ class HotPath:
         mask = torch.empty((Cn,), dtype=torch.uint8, device=self.device)
         invalid = torch.zeros((Cn,), dtype=torch.int32, device=self.device)
         if bins is not None and not write_clim:
-            edges = self._dev(bins.edges, np.float32)
+            edges = self.bin_tables(bins)[0]
             binsb = torch.empty((T_out, Cn), dtype=torch.int16, device=self.device)
             e_ptr, b_ptr, nb = edges.data_ptr(), binsb.data_ptr(), bins.nb
         else:
@@ -146,16 +154,20 @@ class HotPath:
         ws: int,
         ny: int,
         nx: int,
+        rows: Optional[tuple] = None,
     ) -> Dict[str, object]:
+        """``rows=(row0, row1)`` restricts the output to the grid rows a latitude shard owns."""
         self._bind_stream()
         T_out, Cn = binsb.shape
+        row0, row1 = rows if rows is not None else (0, max(ny, 1))
         thr = torch.empty((N_DOY, Cn), dtype=torch.float32, device=self.device)
-        stats = torch.tensor([0xFFFFFFFF - (1 << 32), 0, 0, 0], dtype=torch.int32, device=self.device)
-        centres = self._dev(bins.centres, np.float32)
+        stats = torch.zeros((4,), dtype=torch.int32, device=self.device)
+        stats[0] = -1  # min_key = 0xFFFFFFFF
+        centres = self.bin_tables(bins)[1]
         rc = self.lib.marex_hobday_thresholds_f32(
             self.ctx.handle, binsb.data_ptr(), T_out, Cn, int(ny), int(nx), dcal.doy_start.data_ptr(),
             first_anom.data_ptr(), centres.data_ptr(), bins.nb, float(q), int(wd), int(ws),
-            float(bins.lower_bound), float(bins.upper_bound), thr.data_ptr(), stats.data_ptr(),
+            float(bins.lower_bound), float(bins.upper_bound), int(row0), int(row1), thr.data_ptr(), stats.data_ptr(),
         )
         self.ctx.check(rc, "marex_hobday_thresholds_f32")
         return {"thr_doy_major": thr, "stats_dev": stats, "_keep": centres}
@@ -172,14 +184,18 @@ class HotPath:
         }
 
     # ------------------------------------------------------------------ stage a9 compare
-    def mask_ge_doy(self, anom: torch.Tensor, thr_doy_major: torch.Tensor, dcal: DeviceCalendar) -> Dict[str, torch.Tensor]:
+    def mask_ge_doy(
+        self, anom: torch.Tensor, thr_doy_major: torch.Tensor, dcal: DeviceCalendar, cells: Optional[tuple] = None
+    ) -> Dict[str, torch.Tensor]:
+        """``cells=(c0, c1)`` restricts compare / write / count to the owned cells of a shard."""
         self._bind_stream()
         T_out, Cn = anom.shape
+        c0, c1 = cells if cells is not None else (0, Cn)
         ext = torch.empty((T_out, Cn), dtype=torch.uint8, device=self.device)
         n_true = torch.zeros((1,), dtype=torch.int64, device=self.device)
         rc = self.lib.marex_mask_ge_doy_f32(
             self.ctx.handle, anom.data_ptr(), thr_doy_major.data_ptr(), dcal.doy_start.data_ptr(),
-            dcal.doy_rows.data_ptr(), T_out, Cn, ext.data_ptr(), n_true.data_ptr(),
+            dcal.doy_rows.data_ptr(), T_out, Cn, int(c0), int(c1), ext.data_ptr(), n_true.data_ptr(),
         )
         self.ctx.check(rc, "marex_mask_ge_doy_f32")
         return {"extreme": ext, "n_true": n_true}
@@ -206,11 +222,17 @@ class HotPath:
         ny: int,
         nx: int,
         transpose_thresholds: bool = True,
+        own_rows: Optional[tuple] = None,
     ) -> Dict[str, object]:
-        """validation + anomaly + thresholds + mask for ``shifting_baseline`` / ``hobday_extreme`` (approximate)."""
+        """validation + anomaly + thresholds + mask for ``shifting_baseline`` / ``hobday_extreme`` (approximate).
+
+        ``own_rows=(row0, row1)``: the field is a latitude shard with overlap rows; thresholds and the
+        mask are produced for the owned rows only (:mod:`marex_amd.dist`).
+        """
         a = self.shifting_baseline(x, dcal, W, S, bins)
-        t = self.hobday_thresholds(a["bins"], a["out"], dcal, bins, q, wd, ws, ny, nx)
-        m = self.mask_ge_doy(a["out"], t["thr_doy_major"], dcal)
+        cells = None if own_rows is None else (own_rows[0] * nx, own_rows[1] * nx)
+        t = self.hobday_thresholds(a["bins"], a["out"], dcal, bins, q, wd, ws, ny, nx, rows=own_rows)
+        m = self.mask_ge_doy(a["out"], t["thr_doy_major"], dcal, cells=cells)
         res = {
             "dat_anomaly": a["out"],
             "mask": a["mask"],
@@ -224,3 +246,25 @@ class HotPath:
         if transpose_thresholds:
             res["thresholds"] = self.transpose(t["thr_doy_major"])
         return res
+
+    # ------------------------------------------------------------------ stages not on the device yet
+    def _todo(self, what: str):
+        raise ProcessingError(f"{what} is not implemented on the device path yet")
+
+    def fixed_baseline(self, x, dcal, reference_period, bins, count_invalid=True):
+        self._todo("fixed_baseline anomaly")
+
+    def detrend(self, x, model, pmodel, force_zero_mean, bins_and_cal, count_invalid=True):
+        self._todo("polynomial / harmonic detrend")
+
+    def hobday_thresholds_exact(self, anom, dcal, percentile, wd):
+        self._todo("exact Hobday percentile")
+
+    def global_threshold(self, anom, percentile, method_percentile, bins):
+        self._todo("global_extreme threshold")
+
+    def mask_ge_const(self, anom, thr):
+        self._todo("constant-threshold mask")
+
+    def digitize(self, anom, dcal, bins):
+        self._todo("stand-alone binning")
