@@ -98,6 +98,8 @@ int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64
  *
  *  bins[T_out, C]     uint16 bin ids, rows sorted by (dayofyear, time) (see rowb_index above)
  *  doy_start[367]     rows doy_start[d-1]..doy_start[d]-1 hold dayofyear d
+ *  max_bucket         largest number of rows of one dayofyear (host knows doy_start); lets the kernel use
+ *                     16-bit counters when max_bucket*wd*ws*ws <= 65535.  0 = unknown (32-bit counters)
  *  ny, nx             grid (cells = ny*nx, lon fastest); ny == 0: unstructured, no pooling (ws must be <= 1)
  *  first_anom[C]      first kept anomaly row; NaN there => threshold NaN (detect.py:2704)
  *  centres[nb]        float32 bin centres, centres[0] == 0
@@ -110,7 +112,7 @@ int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64
  *  stats              device struct, must be initialised {0xFFFFFFFF, 0, 0, 0} by the caller
  */
 int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins, int64_t T_out, int64_t C, int ny,
-                                int nx, const int32_t* doy_start, const float* first_anom,
+                                int nx, const int32_t* doy_start, int max_bucket, const float* first_anom,
                                 const float* centres, int nb, double q, int wd, int ws,
                                 float lower_bound, float upper_bound, int row0, int row1,
                                 float* thr_doy_major, marex_thr_stats* stats);

@@ -40,7 +40,7 @@ PROTOTYPES = {
     ),
     "marex_hobday_thresholds_f32": (
         _i32,
-        [_p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i32, _f64, _i32, _i32, _f32, _f32, _i32, _i32, _p, _p],
+        [_p, _p, _i64, _i64, _i32, _i32, _p, _i32, _p, _p, _i32, _f64, _i32, _i32, _f32, _f32, _i32, _i32, _p, _p],
     ),
     "marex_mask_ge_doy_f32": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "marex_transpose_f32": (_i32, [_p, _p, _i64, _i64, _p]),

@@ -481,109 +481,200 @@ extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64
 // ------------------------------------------------------------------------------------------------
 // K_T: day-of-year thresholds from pooled histograms
 //
-// Workgroup = NSEG consecutive cells of one grid row.  It keeps the pooled (ws x ws cells, wd days)
-// histogram of every output cell in LDS and slides it over the day-of-year axis: entering the next
-// day adds one dayofyear bucket of every input cell of the neighbourhood and removes the one that
-// leaves the window (integer counts, order independent => exact).  The quantile bin `iu` and the
-// count below it are tracked incrementally instead of re-scanning the nb bins.
+// One WAVE owns NW consecutive cells of one grid row and runs on its own (no workgroup barrier): it
+// keeps the pooled (ws x ws cells, wd days) histogram of each of its cells in LDS and slides it over
+// the day-of-year axis -- entering a day adds one dayofyear bucket of every cell of the neighbourhood
+// and removes the one that leaves the window (integer counts, order independent => exact).  The
+// quantile bin `iu` and the number of samples at or above it (`ge`) are tracked incrementally, so no
+// pass over the nb bins is needed per day.  Counters are uint16 packed two per dword whenever the
+// largest possible pooled count fits (PACK), halving LDS per cell and doubling the resident waves.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned ordered_key(float v) {
     unsigned b = __float_as_uint(v);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool PACK>
+__device__ __forceinline__ unsigned hget(const unsigned* h, int b) {
+    return PACK ? ((h[b >> 1] >> ((b & 1) * 16)) & 0xFFFFu) : h[b];
+}
+template <bool PACK>
+__device__ __forceinline__ void hadd(unsigned* h, int b, int delta) {
+    if (PACK)
+        atomicAdd(&h[b >> 1], (unsigned)delta * (1u << ((b & 1) * 16)));
+    else
+        atomicAdd(&h[b], (unsigned)delta);
+}
+
+template <bool PACK>
 __global__ void __launch_bounds__(256)
-k_thresholds(const unsigned short* __restrict__ bins, long C, int ny, int nx, int nseg_per_row, int NSEG,
-             const int* __restrict__ doy_start, const float* __restrict__ first_anom,
+k_thresholds(const unsigned short* __restrict__ bins, long C, int ny, int nx, int nseg_per_row, long nsegs,
+             int NW, const int* __restrict__ doy_start, const float* __restrict__ first_anom,
              const float* __restrict__ centres, int nb, double q, int wd, int p, float lower_bound,
              float upper_bound, int row0, float* __restrict__ thr, marex_thr_stats* __restrict__ stats) {
     extern __shared__ unsigned lds_u[];
-    unsigned* hist = lds_u;                      // [NSEG][nb]
-    int* st_iu = (int*)(hist + (size_t)NSEG * nb);  // [NSEG]
-    int* st_below = st_iu + NSEG;                // [NSEG]
-    int* st_tot = st_below + NSEG;               // [NSEG]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long seg = (long)blockIdx.x * 4 + wave;
+    if (seg >= nsegs) return;  // no workgroup barrier anywhere below
+    const int nbw = PACK ? (nb + 1) / 2 : nb;
+    const int wave_words = NW * nbw + 3 * NW;
+    unsigned* hist = lds_u + (size_t)wave * wave_words;  // [NW][nbw]
+    int* st_iu = (int*)(hist + (size_t)NW * nbw);           // [NW] quantile bin
+    int* st_ge = st_iu + NW;                                // [NW] samples with bin >= iu
+    int* st_tot = st_ge + NW;                               // [NW] samples in the window
 
-    const int tid = threadIdx.x;
-    const int j = (ny > 0) ? row0 + (int)(blockIdx.x / nseg_per_row) : 0;
-    const int seg = (int)(blockIdx.x % nseg_per_row);
-    const int i0 = seg * NSEG;
-    const int nout = (nx - i0) < NSEG ? (nx - i0) : NSEG;
+    const int j = (ny > 0) ? row0 + (int)(seg / nseg_per_row) : 0;
+    const int i0 = (int)(seg % nseg_per_row) * NW;
+    const int nout = (nx - i0) < NW ? (nx - i0) : NW;
     const int jlo = (j - p) < 0 ? 0 : j - p;
     const int jhi = (ny > 0) ? ((j + p) > ny - 1 ? ny - 1 : j + p) : 0;
-    const int R = jhi - jlo + 1;
-    const int win = nout + 2 * p;          // input columns i0-p .. i0+nout-1+p (lon periodic)
-    const int ncell_in = R * win;
+    const int win = nout + 2 * p;  // input columns i0-p .. i0+nout-1+p (lon periodic)
+    const int ncell_in = (jhi - jlo + 1) * win;
     const int pd = wd / 2;
+    const int nslot = ncell_in >= 64 ? 1 : 64 / ncell_in;
 
-    for (int i = tid; i < NSEG * nb; i += 256) hist[i] = 0u;
-    for (int i = tid; i < 3 * NSEG; i += 256) st_iu[i] = 0;
-    __syncthreads();
+    for (int i = lane; i < wave_words; i += 64) hist[i] = 0u;
+    wave_sync();
 
-    // add (sgn=+1) or remove (sgn=-1) the samples of dayofyear `d1` (1-based) of the whole neighbourhood
-    auto apply_bucket = [&](int d1, int sgn) {
-        const int r0 = doy_start[d1 - 1], r1 = doy_start[d1];
-        for (int ic = tid; ic < ncell_in; ic += 256) {
+    // Per-lane view of the neighbourhood, fixed for the whole day loop: which input cell(s) this lane
+    // streams, where its bin column starts, and which of the wave's output cells it feeds.
+    struct CellMap {
+        long coloff;  // cell index into a bins row, -1: lane idle in this pass
+        int o_lo, o_hi;
+    };
+    auto make_map = [&](int ic) {
+        CellMap m;
+        m.coloff = -1;
+        m.o_lo = 0;
+        m.o_hi = -1;
+        if (ic >= 0 && ic < ncell_in) {
             const int rr = ic / win, ii = ic - rr * win;
             int gi = (i0 - p + ii) % nx;
             if (gi < 0) gi += nx;
-            const long cell = (long)(jlo + rr) * nx + gi;
-            int o_lo = ii - 2 * p;
-            if (o_lo < 0) o_lo = 0;
-            int o_hi = ii < nout - 1 ? ii : nout - 1;
-            for (int r = r0; r < r1; ++r) {
-                const int b = bins[(size_t)r * C + cell];
-                if (b >= nb) continue;
-                for (int o = o_lo; o <= o_hi; ++o) {
-                    atomicAdd(&hist[(size_t)o * nb + b], (unsigned)sgn);
-                    atomicAdd(&st_tot[o], sgn);
-                    if (b < st_iu[o]) atomicAdd(&st_below[o], sgn);
-                }
+            m.coloff = (long)(jlo + rr) * nx + gi;
+            m.o_lo = (ii - 2 * p) < 0 ? 0 : ii - 2 * p;
+            m.o_hi = ii < nout - 1 ? ii : nout - 1;
+        }
+        return m;
+    };
+    const int slot = nslot > 1 ? lane / ncell_in : 0;
+    const int npass = nslot > 1 ? 1 : (ncell_in + 63) / 64;
+    const CellMap map0 = make_map(nslot > 1 ? (slot < nslot ? lane % ncell_in : -1) : lane);
+    const CellMap map1 = make_map(npass > 1 ? 64 + lane : -1);
+
+    // One sample of a bucket: bins 0 / 1 (about half of all samples) are only counted here and
+    // flushed once per lane and step; every other bin goes to the histograms of the fed cells.
+    auto one_sample = [&](const CellMap& m, int b, int sgn, int& nvalid, int& n0, int& n1) {
+        if (b >= nb) return;
+        nvalid += sgn;
+        if (b == 0) {
+            n0 += sgn;
+        } else if (b == 1) {
+            n1 += sgn;
+        } else {
+            unsigned* h = hist + (size_t)m.o_lo * nbw;
+            for (int o = m.o_lo; o <= m.o_hi; ++o, h += nbw) {
+                hadd<PACK>(h, b, sgn);
+                if (b >= st_iu[o]) atomicAdd(&st_ge[o], sgn);
             }
         }
     };
+    // stream one bucket (rows r0 .. r0+nd-1 of the lane's column), 4 independent loads in flight
+    auto stream_bucket = [&](const CellMap& m, int r0, int nd, int sgn, int& nvalid, int& n0, int& n1) {
+        const unsigned short* col = bins + (size_t)r0 * C + m.coloff;
+        for (int r = slot; r < nd; r += 4 * nslot) {
+            int bb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ru = r + u * nslot;
+                bb[u] = ru < nd ? (int)col[(size_t)ru * C] : nb;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) one_sample(m, bb[u], sgn, nvalid, n0, n1);
+        }
+    };
+    auto flush = [&](const CellMap& m, int nvalid, int n0, int n1) {
+        if ((nvalid | n0 | n1) == 0) return;
+        unsigned* h = hist + (size_t)m.o_lo * nbw;
+        for (int o = m.o_lo; o <= m.o_hi; ++o, h += nbw) {
+            if (nvalid) atomicAdd(&st_tot[o], nvalid);
+            if (PACK) {
+                if (n0 | n1) atomicAdd(&h[0], (unsigned)(n0 + n1 * 65536));
+            } else {
+                if (n0) atomicAdd(&h[0], (unsigned)n0);
+                if (n1) atomicAdd(&h[1], (unsigned)n1);
+            }
+            const int iu = st_iu[o];
+            const int g = (iu <= 0 ? n0 : 0) + (iu <= 1 ? n1 : 0);
+            if (g) atomicAdd(&st_ge[o], g);
+        }
+    };
+    // enter dayofyear d_in (1-based, 0 = none) and leave d_out (0 = none) for the whole neighbourhood
+    auto step_window = [&](int d_in, int d_out) {
+        const int ri = d_in ? doy_start[d_in - 1] : 0, ni = d_in ? doy_start[d_in] - ri : 0;
+        const int ro = d_out ? doy_start[d_out - 1] : 0, no = d_out ? doy_start[d_out] - ro : 0;
+        for (int pass = 0; pass < npass; ++pass) {
+            const CellMap m = pass == 0 ? map0 : (pass == 1 ? map1 : make_map(pass * 64 + lane));
+            if (m.coloff < 0) continue;
+            int nvalid = 0, n0 = 0, n1 = 0;
+            stream_bucket(m, ri, ni, +1, nvalid, n0, n1);
+            stream_bucket(m, ro, no, -1, nvalid, n0, n1);
+            flush(m, nvalid, n0, n1);
+        }
+    };
 
-    for (int o = -pd; o <= pd; ++o) apply_bucket(((0 + o) % NDOY + NDOY) % NDOY + 1, +1);
-    __syncthreads();
+    for (int o = -pd; o <= pd; ++o) step_window((o % NDOY + NDOY) % NDOY + 1, 0);
+    wave_sync();
 
     unsigned kmin = 0xFFFFFFFFu, kmax = 0u, nlow = 0u, nhigh = 0u;
+    const long cell = (long)j * nx + i0 + lane;
+    bool land = true;
+    if (lane < nout) land = !(first_anom[cell] == first_anom[cell]);
     for (int d = 0; d < NDOY; ++d) {
         if (d > 0) {
-            apply_bucket((d + pd) % NDOY + 1, +1);
-            apply_bucket(((d - pd - 1) % NDOY + NDOY) % NDOY + 1, -1);
-            __syncthreads();
+            step_window((d + pd) % NDOY + 1, ((d - pd - 1) % NDOY + NDOY) % NDOY + 1);
+            wave_sync();
         }
-        if (tid < nout) {
-            const unsigned* h = hist + (size_t)tid * nb;
-            const int tot = st_tot[tid];
-            int iu = st_iu[tid], below = st_below[tid];
-            const double qpos = q * (double)tot;
+        if (lane < nout) {
+            const unsigned* h = hist + (size_t)lane * nbw;
+            const int tot = st_tot[lane];
+            int iu = st_iu[lane], ge = st_ge[lane];
             float t32 = nan_f();
             if (tot > 0) {
-                while (iu < nb - 1 && (double)(below + (int)h[iu]) <= qpos) {
-                    below += (int)h[iu];
+                const double qpos = q * (double)tot;
+                while (iu < nb - 1) {
+                    const int hv = (int)hget<PACK>(h, iu);
+                    if (!((double)(tot - ge + hv) <= qpos)) break;
+                    ge -= hv;
                     ++iu;
                 }
-                while (iu > 0 && (double)below > qpos) {
+                while (iu > 0 && (double)(tot - ge) > qpos) {
                     --iu;
-                    below -= (int)h[iu];
+                    ge += (int)hget<PACK>(h, iu);
                 }
-                const int il = iu > 0 ? iu - 1 : 0;
-                const int cs_iu = below + (int)h[iu];
-                const int cs_il = iu > 0 ? below : cs_iu;
-                const int diff = cs_iu - cs_il;
-                const double frac = diff > 0 ? (qpos - (double)cs_il) / (double)diff : 0.5;
-                const float dc = centres[iu] - centres[il];
-                const double prod = frac * (double)dc;
-                t32 = (float)((double)centres[il] + prod);
-                if (iu == 0) t32 = centres[0];
+                if (!land) {
+                    const int below = tot - ge;
+                    const int il = iu > 0 ? iu - 1 : 0;
+                    const int cs_iu = below + (int)hget<PACK>(h, iu);
+                    const int cs_il = iu > 0 ? below : cs_iu;
+                    const int diff = cs_iu - cs_il;
+                    const double frac = diff > 0 ? (qpos - (double)cs_il) / (double)diff : 0.5;
+                    const float dc = centres[iu] - centres[il];
+                    const double prod = frac * (double)dc;
+                    t32 = (float)((double)centres[il] + prod);
+                    if (iu == 0) t32 = centres[0];
+                }
             } else {
                 iu = 0;
-                below = 0;
+                ge = 0;
             }
-            st_iu[tid] = iu;
-            st_below[tid] = below;
-            const long cell = (long)j * nx + i0 + tid;
-            if (!(first_anom[cell] == first_anom[cell])) t32 = nan_f();
+            st_iu[lane] = iu;
+            st_ge[lane] = ge;
             if (t32 == t32) {
                 const unsigned k = ordered_key(t32);
                 kmin = k < kmin ? k : kmin;
@@ -596,9 +687,286 @@ k_thresholds(const unsigned short* __restrict__ bins, long C, int ny, int nx, in
             }
             thr[(size_t)d * C + cell] = t32;
         }
-        __syncthreads();
+        wave_sync();
     }
-    if (tid < nout) {
+    if (lane < nout) {
+        if (kmin != 0xFFFFFFFFu) atomicMin(&stats->min_key, kmin);
+        if (kmax != 0u) atomicMax(&stats->max_key, kmax);
+        if (nlow) atomicAdd(&stats->n_too_low, nlow);
+        if (nhigh) atomicAdd(&stats->n_too_high, nhigh);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_T (band algorithm, the default): thresholds from per-cell windowed CUMULATIVE level counts.
+//
+// Workgroup = one tile of TR x TC = 256 grid cells (outputs are the inner (TR-2p) x (TC-2p) cells,
+// the rim only feeds the ws x ws pooling) and a block of up to 16 consecutive dayofyears.
+// Lane t owns cell t: its LDS column lev[.][t] holds, for the current day, the number of samples of
+// the wd-day window of THAT cell with level <= k, for every level k (uint16, two levels per dword;
+// the column is private to the lane, so building it needs no atomics and is bank-conflict free).
+//   P1  day 0 of the block: count the wd buckets from scratch; later days: undo the prefix sum, add
+//       the entering bucket, remove the leaving one; prefix-sum again.
+//   P2  every output lane finds the smallest level whose POOLED cumulative count (sum of the 25
+//       neighbour columns at that level, integer => exact) exceeds q*total, starting from the
+//       previous day's level (2-4 probes of (2p+1)^2 LDS reads instead of scanning all bins).
+// Pass 0 uses coarse levels (groups of 2^shift bins) and yields the group holding the quantile bin
+// for every (cell, day); the following pass(es) use one level per bin inside the band of groups the
+// tile actually needs (<= 64 bins per pass) and produce the exact iu, cs[iu-1], cs[iu] of
+// detect.py:2510-2550.  Work per (cell, day) is O(levels + samples entering/leaving), independent
+// of the 25-fold spatial fan-out that dominates the sliding-histogram kernel above.
+// ------------------------------------------------------------------------------------------------
+#define TB_MAXLEV 66
+#define TB_NLP 33
+#define TB_DMAX 16
+
+__global__ void __launch_bounds__(256)
+k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int row0, int row1, int tiles_x,
+           int TR, int TC, int Dd, int shift, const int* __restrict__ doy_start,
+           const float* __restrict__ first_anom, const float* __restrict__ centres, int nb, double q, int wd,
+           int p, float lower_bound, float upper_bound, float* __restrict__ thr,
+           marex_thr_stats* __restrict__ stats) {
+    __shared__ unsigned lev[TB_NLP][256];
+    __shared__ unsigned char gst[TB_DMAX][256];
+    __shared__ int s_gmin, s_gmax;
+
+    const int t = threadIdx.x;
+    const int tr = t / TC, tc = t - tr * TC;
+    const int OR = TR - 2 * p, OC = TC - 2 * p;
+    const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
+    const int jt0 = row0 + ty * OR, it0 = tx * OC;
+    const int j = (ny > 0) ? jt0 - p + tr : 0;
+    const int icol = it0 - p + tc;
+    bool cell_valid;
+    long cell;
+    if (ny > 0) {
+        int gi = icol % nx;
+        if (gi < 0) gi += nx;
+        cell_valid = (j >= 0 && j < ny);
+        cell = (long)j * nx + gi;
+    } else {
+        cell_valid = icol < nx;
+        cell = icol;
+    }
+    const bool is_out = tr >= p && tr < TR - p && tc >= p && tc < TC - p && j < row1 && icol < nx;
+    const int d_begin = (int)blockIdx.y * Dd;
+    const int ndays = (NDOY - d_begin) < Dd ? (NDOY - d_begin) : Dd;
+    const int pd = wd / 2;
+    const int ngroups = ((nb - 1) >> shift) + 1;
+    const int gpp = 64 >> shift;  // groups per fine pass (>= 1): band of gpp << shift <= 64 bins
+    bool land = true;
+    if (is_out) land = !(first_anom[cell] == first_anom[cell]);
+
+    for (int r = 0; r < TB_NLP; ++r) lev[r][t] = 0u;
+    if (t == 0) {
+        s_gmin = 255;
+        s_gmax = -1;
+    }
+
+    // level mapping of the current pass
+    bool fine = false;
+    int B0 = 0, BW = 0, nlev = ngroups;
+    auto lvl = [&](int b) {
+        if (!fine) return b >> shift;
+        const int k = b - B0;
+        return k < 0 ? 0 : (k >= BW ? BW + 1 : k + 1);
+    };
+    // add (sgn=+1) / remove (sgn=-1) the bucket of dayofyear index d0 (0-based) of this lane's cell
+    auto add_bucket = [&](int d0, int sgn) {
+        const int r0 = doy_start[d0], nd = doy_start[d0 + 1] - r0;
+        const unsigned short* col = bins + (size_t)r0 * C + cell;
+        for (int r = 0; r < nd; r += 4) {
+            int bb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bb[u] = (r + u < nd) ? (int)col[(size_t)(r + u) * C] : nb;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (bb[u] < nb) {
+                    const int k = lvl(bb[u]);
+                    atomicAdd(&lev[k >> 1][t], (unsigned)sgn * (1u << ((k & 1) * 16)));
+                }
+            }
+        }
+    };
+    auto prefix = [&](int nlp) {
+        unsigned run = 0;
+        for (int r = 0; r < nlp; ++r) {
+            const unsigned w = lev[r][t];
+            const unsigned a = (w & 0xFFFFu) + run, b = (w >> 16) + a;
+            run = b;
+            lev[r][t] = a | (b << 16);
+        }
+    };
+    auto unprefix = [&](int nlp) {
+        unsigned prev = 0;
+        for (int r = 0; r < nlp; ++r) {
+            const unsigned w = lev[r][t];
+            const unsigned a = w & 0xFFFFu, b = w >> 16;
+            lev[r][t] = (a - prev) | ((b - a) << 16);
+            prev = b;
+        }
+    };
+    // pooled cumulative count at level k of this lane's (2p+1)^2 neighbourhood
+    auto pooled = [&](int k) {
+        const unsigned* row = &lev[k >> 1][t];
+        const int sh16 = (k & 1) * 16;
+        int s = 0;
+        for (int dr = -p; dr <= p; ++dr)
+            for (int dc = -p; dc <= p; ++dc) s += (int)((row[dr * TC + dc] >> sh16) & 0xFFFFu);
+        return s;
+    };
+    // smallest k in [klo, khi) with pooled(k) > qpos (khi if none).  With `counts`: ck = pooled(k) and
+    // cb = pooled(k-1) (0 for k == 0) on return.
+    auto find_level = [&](int hint, int klo, int khi, double qpos, bool counts, int& ck, int& cb) {
+        int k;
+        bool have_cb = false;
+        ck = 0;
+        cb = 0;
+        if (hint < klo || hint >= khi) {  // no usable hint: bisection over [klo, khi]
+            int lo = klo, hi = khi;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if ((double)pooled(mid) > qpos)
+                    hi = mid;
+                else
+                    lo = mid + 1;
+            }
+            k = lo;
+            if (counts && k < khi) ck = pooled(k);
+        } else {
+            k = hint;
+            ck = pooled(k);
+            if ((double)ck > qpos) {
+                while (k > klo) {
+                    const int cm = pooled(k - 1);
+                    if ((double)cm > qpos) {
+                        --k;
+                        ck = cm;
+                    } else {
+                        cb = cm;
+                        have_cb = true;
+                        break;
+                    }
+                }
+            } else {
+                do {
+                    cb = ck;
+                    have_cb = true;
+                    ++k;
+                    if (k >= khi) break;
+                    ck = pooled(k);
+                } while (!((double)ck > qpos));
+            }
+        }
+        if (counts && !have_cb && k > 0) cb = pooled(k - 1);
+        return k;
+    };
+
+    unsigned kmin = 0xFFFFFFFFu, kmax = 0u, nlow = 0u, nhigh = 0u;
+    int g_base = 0, g_last = -1;
+    for (int pass = 0;; ++pass) {
+        if (pass == 0) {
+            fine = false;
+            nlev = ngroups;
+        } else {
+            fine = true;
+            B0 = g_base << shift;
+            BW = gpp << shift;
+            if (B0 + BW > nb) BW = nb - B0;
+            nlev = BW + 2;
+        }
+        const int nlp = (nlev + 1) >> 1;
+        int hint = -1;
+        for (int dd = 0; dd < ndays; ++dd) {
+            const int d = d_begin + dd;
+            // ---------------- P1: this lane's column
+            if (cell_valid) {
+                if (dd == 0) {
+                    for (int r = 0; r < nlp; ++r) lev[r][t] = 0u;
+                    for (int o = -pd; o <= pd; ++o) add_bucket(((d + o) % NDOY + NDOY) % NDOY, +1);
+                } else {
+                    unprefix(nlp);
+                    add_bucket((d + pd) % NDOY, +1);
+                    add_bucket(((d - pd - 1) % NDOY + NDOY) % NDOY, -1);
+                }
+                prefix(nlp);
+            }
+            __syncthreads();
+            // ---------------- P2: quantile level of this lane's output cell
+            if (is_out) {
+                if (pass == 0) {
+                    int g = 255;
+                    if (!land) {
+                        const int tot = pooled(nlev - 1);
+                        if (tot > 0) {
+                            int ck, cb;
+                            const double qpos = q * (double)tot;
+                            g = find_level(hint, 0, nlev, qpos, false, ck, cb);
+                            if (g >= nlev) g = nlev - 1;  // nothing above qpos: iu clips to nb-1
+                            hint = g;
+                            atomicMin(&s_gmin, g);
+                            atomicMax(&s_gmax, g);
+                        }
+                    }
+                    gst[dd][t] = (unsigned char)g;
+                    if (g == 255) thr[(size_t)d * C + cell] = nan_f();  // land or empty window
+                } else {
+                    const int g = gst[dd][t];
+                    if (g != 255 && g >= g_base && g < g_base + gpp) {
+                        const int tot = pooled(nlev - 1);
+                        const double qpos = q * (double)tot;
+                        int ck, cb;
+                        int k = find_level(hint, 1, BW + 1, qpos, true, ck, cb);
+                        int iu = B0 + k - 1;
+                        if (k > BW) {  // no bin exceeds qpos (q == 1): searchsorted gives nb, clipped to nb-1
+                            iu = nb - 1;
+                            k = iu - B0 + 1;
+                            ck = pooled(k);
+                            cb = pooled(k - 1);
+                        }
+                        hint = k;
+                        const int il = iu > 0 ? iu - 1 : 0;
+                        const int cs_iu = ck;
+                        const int cs_il = iu > 0 ? cb : ck;
+                        const int diff = cs_iu - cs_il;
+                        const double frac = diff > 0 ? (qpos - (double)cs_il) / (double)diff : 0.5;
+                        const float dc = centres[iu] - centres[il];
+                        const double prod = frac * (double)dc;
+                        float t32 = (float)((double)centres[il] + prod);
+                        if (iu == 0) t32 = centres[0];
+                        const unsigned key = ordered_key(t32);
+                        kmin = key < kmin ? key : kmin;
+                        kmax = key > kmax ? key : kmax;
+                        if (t32 > upper_bound) ++nhigh;
+                        if (t32 < lower_bound) {
+                            ++nlow;
+                            t32 = lower_bound;
+                        }
+                        thr[(size_t)d * C + cell] = t32;
+                    } else {
+                        hint = -1;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (pass == 0) {
+            g_base = s_gmin;
+            g_last = s_gmax;
+        } else {
+            g_base += gpp;
+        }
+        if (g_base > g_last) break;  // also: nothing but land / empty windows in this tile
+    }
+    // statistics: wave reduction, one set of global atomics per wave
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        const unsigned a = __shfl_down(kmin, sft, 64), b = __shfl_down(kmax, sft, 64);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+        nlow += __shfl_down(nlow, sft, 64);
+        nhigh += __shfl_down(nhigh, sft, 64);
+    }
+    if ((t & 63) == 0) {
         if (kmin != 0xFFFFFFFFu) atomicMin(&stats->min_key, kmin);
         if (kmax != 0u) atomicMax(&stats->max_key, kmax);
         if (nlow) atomicAdd(&stats->n_too_low, nlow);
@@ -607,9 +975,9 @@ k_thresholds(const unsigned short* __restrict__ bins, long C, int ny, int nx, in
 }
 
 extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins, int64_t T_out, int64_t C, int ny,
-                                           int nx, const int32_t* doy_start, const float* first_anom,
-                                           const float* centres, int nb, double q, int wd, int ws,
-                                           float lower_bound, float upper_bound, int row0, int row1,
+                                           int nx, const int32_t* doy_start, int max_bucket,
+                                           const float* first_anom, const float* centres, int nb, double q, int wd,
+                                           int ws, float lower_bound, float upper_bound, int row0, int row1,
                                            float* thr_doy_major, marex_thr_stats* stats) {
     if (!ctx) return -1;
     if (!bins || !doy_start || !first_anom || !centres || !thr_doy_major || !stats || T_out <= 0 || C <= 0)
@@ -630,20 +998,52 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
     }
     if (nb < 4 || nb > 36000) return fail(ctx, -4, "marex_hobday_thresholds_f32: nb must be in 4..36000");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int NSEG = env_int("MAREX_THR_NSEG", 32);
-    const size_t budget = 72 * 1024;
-    while (NSEG > 1 && (size_t)NSEG * (nb + 3) * 4 > budget) NSEG >>= 1;
-    if (NSEG > nx) NSEG = nx;
-    const size_t lds = (size_t)NSEG * (nb + 3) * 4;
-    const int nseg_per_row = (nx + NSEG - 1) / NSEG;
-    const unsigned nblocks = (unsigned)nseg_per_row * (unsigned)(row1 - row0);
+
+    // ---- band algorithm (default) whenever its uint16 level counters and 64-bin bands suffice
+    int shift = 0;
+    while ((((nb - 1) >> shift) + 1) > 64) ++shift;
+    const int algo = env_int("MAREX_THR_ALGO", 0);  // 0 auto, 1 force sliding histograms
+    const bool band_ok = (1 << shift) <= 64 && ws / 2 <= 6 && max_bucket > 0 && (int64_t)max_bucket * wd <= 65535;
+    if (algo != 1 && band_ok) {
+        const int p = ws / 2;
+        const int TR = (ny > 0 && p > 0) ? 16 : 1, TC = 256 / TR;
+        const int OR = TR - 2 * p, OC = TC - 2 * p;
+        int Dd = env_int("MAREX_THR_DD", TB_DMAX);
+        if (Dd < 1 || Dd > TB_DMAX) Dd = TB_DMAX;
+        const int tiles_x = (nx + OC - 1) / OC, tiles_y = (row1 - row0 + OR - 1) / OR;
+        dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((NDOY + Dd - 1) / Dd));
+        {
+            LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
+            hipLaunchKernelGGL(k_thr_band, grid, dim3(256), 0, ctx->stream, bins, (long)C, ny, nx, row0, row1,
+                               tiles_x, TR, TC, Dd, shift, doy_start, first_anom, centres, nb, q, wd, p,
+                               lower_bound, upper_bound, thr_doy_major, stats);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    }
+
+    // ---- sliding pooled histograms (any nb / ws / bucket size)
+    // uint16 counters are enough when even "all samples of the pooled window in one bin" fits
+    const bool pack = max_bucket > 0 && (int64_t)max_bucket * wd * ws * ws <= 65535 && !env_int("MAREX_THR_U32", 0);
+    const int nbw = pack ? (nb + 1) / 2 : nb;
+    int NW = env_int("MAREX_THR_NW", 16);
+    if (NW < 1 || NW > 64) NW = 16;
+    const size_t budget = 80 * 1024;  // per workgroup of 4 waves: two workgroups per CU
+    while (NW > 1 && 4 * (size_t)NW * (nbw + 3) * 4 > budget) NW >>= 1;
+    if (NW > nx) NW = nx;
+    const size_t lds = 4 * (size_t)NW * (nbw + 3) * 4;
+    if (lds > 160 * 1024) return fail(ctx, -4, "marex_hobday_thresholds_f32: %d bins need more than 160 KiB of LDS", nb);
+    const int nseg_per_row = (nx + NW - 1) / NW;
+    const long nsegs = (long)nseg_per_row * (row1 - row0);
+    const unsigned nblocks = (unsigned)((nsegs + 3) / 4);
+    auto kern = pack ? k_thresholds<true> : k_thresholds<false>;
     if (lds > 48 * 1024)
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_thresholds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
-        hipLaunchKernelGGL(k_thresholds, dim3(nblocks), dim3(256), lds, ctx->stream, bins, (long)C, ny, nx,
-                           nseg_per_row, NSEG, doy_start, first_anom, centres, nb, q, wd, ws / 2, lower_bound,
-                           upper_bound, row0, thr_doy_major, stats);
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, ctx->stream, bins, (long)C, ny, nx, nseg_per_row,
+                           nsegs, NW, doy_start, first_anom, centres, nb, q, wd, ws / 2, lower_bound, upper_bound,
+                           row0, thr_doy_major, stats);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -651,40 +1051,62 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
 
 // ------------------------------------------------------------------------------------------------
 // K_M: extreme[t, c] = anom[t, c] >= thr[doy(t), c]
-// One workgroup = (VEC*256 cells, one dayofyear): the threshold row is read once and reused for all
-// timesteps of that dayofyear; 16-byte loads of the anomaly row, 4-byte stores of the mask.
+// One workgroup = (VEC*256 cells, a chunk of consecutive dayofyears).  Rows are visited grouped by
+// dayofyear so that one threshold row serves all its timesteps out of registers; 16-byte loads of the
+// anomaly row, 4-byte stores of the mask, MASK_UNROLL independent rows in flight per lane.
 // ------------------------------------------------------------------------------------------------
+#define MASK_DOY_CHUNKS 6
 template <int VEC>
 __global__ void __launch_bounds__(256)
 k_mask_ge(const float* __restrict__ anom, const float* __restrict__ thr, const int* __restrict__ doy_start,
           const int* __restrict__ doy_rows, long C, long c0, long c1, unsigned char* __restrict__ out,
           unsigned long long* __restrict__ n_true) {
-    const int d = blockIdx.y;
+    const int dA = (int)blockIdx.y * NDOY / MASK_DOY_CHUNKS, dB = ((int)blockIdx.y + 1) * NDOY / MASK_DOY_CHUNKS;
     const long c = c0 + ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
-    const int r0 = doy_start[d], r1 = doy_start[d + 1];
     unsigned cnt = 0;
     if (c < c1) {
-        if (VEC == 4) {
-            const float4 th = *reinterpret_cast<const float4*>(thr + (size_t)d * C + c);
-#pragma unroll 4
-            for (int r = r0; r < r1; ++r) {
-                const size_t off = (size_t)doy_rows[r] * C + c;
-                const float4 a = *reinterpret_cast<const float4*>(anom + off);
-                uchar4 m;
-                m.x = a.x >= th.x;
-                m.y = a.y >= th.y;
-                m.z = a.z >= th.z;
-                m.w = a.w >= th.w;
-                cnt += m.x + m.y + m.z + m.w;
-                *reinterpret_cast<uchar4*>(out + off) = m;
-            }
-        } else {
-            const float th = thr[(size_t)d * C + c];
-            for (int r = r0; r < r1; ++r) {
-                const size_t off = (size_t)doy_rows[r] * C + c;
-                const unsigned char m = anom[off] >= th;
-                cnt += m;
-                out[off] = m;
+        for (int d = dA; d < dB; ++d) {
+            const int r0 = doy_start[d], r1 = doy_start[d + 1];
+            if (VEC == 4) {
+                const float4 th = *reinterpret_cast<const float4*>(thr + (size_t)d * C + c);
+                int r = r0;
+                for (; r + 4 <= r1; r += 4) {
+                    size_t off[4];
+                    float4 a[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) off[u] = (size_t)doy_rows[r + u] * C + c;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(anom + off[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        uchar4 m;
+                        m.x = a[u].x >= th.x;
+                        m.y = a[u].y >= th.y;
+                        m.z = a[u].z >= th.z;
+                        m.w = a[u].w >= th.w;
+                        cnt += m.x + m.y + m.z + m.w;
+                        *reinterpret_cast<uchar4*>(out + off[u]) = m;
+                    }
+                }
+                for (; r < r1; ++r) {
+                    const size_t off = (size_t)doy_rows[r] * C + c;
+                    const float4 a = *reinterpret_cast<const float4*>(anom + off);
+                    uchar4 m;
+                    m.x = a.x >= th.x;
+                    m.y = a.y >= th.y;
+                    m.z = a.z >= th.z;
+                    m.w = a.w >= th.w;
+                    cnt += m.x + m.y + m.z + m.w;
+                    *reinterpret_cast<uchar4*>(out + off) = m;
+                }
+            } else {
+                const float th = thr[(size_t)d * C + c];
+                for (int r = r0; r < r1; ++r) {
+                    const size_t off = (size_t)doy_rows[r] * C + c;
+                    const unsigned char m = anom[off] >= th;
+                    cnt += m;
+                    out[off] = m;
+                }
             }
         }
     }
@@ -707,11 +1129,11 @@ extern "C" int marex_mask_ge_doy_f32(marex_ctx* ctx, const float* anom, const fl
     {
         LaunchTimer lt(ctx, MAREX_K_MASK);
         if (vec) {
-            dim3 grid((unsigned)((nc / 4 + 255) / 256), NDOY);
+            dim3 grid((unsigned)((nc / 4 + 255) / 256), MASK_DOY_CHUNKS);
             hipLaunchKernelGGL(k_mask_ge<4>, grid, dim3(256), 0, ctx->stream, anom, thr_doy_major, doy_start, doy_rows,
                                (long)C, (long)c0, (long)c1, extreme, n_true);
         } else {
-            dim3 grid((unsigned)((nc + 255) / 256), NDOY);
+            dim3 grid((unsigned)((nc + 255) / 256), MASK_DOY_CHUNKS);
             hipLaunchKernelGGL(k_mask_ge<1>, grid, dim3(256), 0, ctx->stream, anom, thr_doy_major, doy_start, doy_rows,
                                (long)C, (long)c0, (long)c1, extreme, n_true);
         }

@@ -166,7 +166,7 @@ class HotPath:
         centres = self.bin_tables(bins)[1]
         rc = self.lib.marex_hobday_thresholds_f32(
             self.ctx.handle, binsb.data_ptr(), T_out, Cn, int(ny), int(nx), dcal.doy_start.data_ptr(),
-            first_anom.data_ptr(), centres.data_ptr(), bins.nb, float(q), int(wd), int(ws),
+            int(np.diff(dcal.plan.doy_start).max()), first_anom.data_ptr(), centres.data_ptr(), bins.nb, float(q), int(wd), int(ws),
             float(bins.lower_bound), float(bins.upper_bound), int(row0), int(row1), thr.data_ptr(), stats.data_ptr(),
         )
         self.ctx.check(rc, "marex_hobday_thresholds_f32")

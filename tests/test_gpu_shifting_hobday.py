@@ -110,3 +110,36 @@ def test_weird_cells(hot):
 
     r = run_case(hot, "1998-03-01", 14 * 365 + 4, 6, 12, 6, 21, 11, 5, mutate=mutate)
     check_all(*r)
+
+
+def test_threshold_kernel_variants(hot, monkeypatch):
+    """Band algorithm with other day-block lengths and the sliding-histogram kernel (16/32-bit counters,
+    other segment widths) all give the same bits as the default."""
+    envs = (
+        {"MAREX_THR_DD": "1"}, {"MAREX_THR_DD": "5"},
+        {"MAREX_THR_ALGO": "1"}, {"MAREX_THR_ALGO": "1", "MAREX_THR_U32": "1"},
+        {"MAREX_THR_ALGO": "1", "MAREX_THR_NW": "5"}, {"MAREX_THR_ALGO": "1", "MAREX_THR_NW": "64", "MAREX_THR_U32": "1"},
+    )
+    for env in envs:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = run_case(hot, "2003-01-01", 9 * 365 + 2, 7, 21, 4, 21, 11, 5)
+        check_all(*r)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+def test_threshold_edge_quantiles_and_windows(hot):
+    """q = 1.0 (searchsorted runs off the end), low q, wide day / spatial windows, tiny grids."""
+    for pct, wd, ws, ny, nx in ((100.0, 11, 5, 6, 10), (60.0, 31, 3, 5, 9), (99.0, 5, 7, 20, 37), (95.0, 11, 5, 3, 4)):
+        r = run_case(hot, "2001-01-01", 11 * 365 + 3, ny, nx, 3, 21, wd, ws, pct=pct)
+        check_all(*r)
+
+
+def test_shifting_chunk_variants(hot, monkeypatch):
+    """Every dayofyear-chunk width of the anomaly kernel gives identical bits."""
+    for D in ("1", "2", "8"):
+        monkeypatch.setenv("MAREX_SHIFT_D", D)
+        r = run_case(hot, "2003-01-01", 9 * 365 + 2, 7, 21, 4, 21, 11, 5)
+        check_all(*r)
+    monkeypatch.delenv("MAREX_SHIFT_D")
