@@ -716,27 +716,28 @@ k_thresholds(const unsigned short* __restrict__ bins, long C, int ny, int nx, in
 // detect.py:2510-2550.  Work per (cell, day) is O(levels + samples entering/leaving), independent
 // of the 25-fold spatial fan-out that dominates the sliding-histogram kernel above.
 // ------------------------------------------------------------------------------------------------
-#define TB_MAXLEV 66
 #define TB_NLP 33
 #define TB_DMAX 16
+#define TB_PRE 8
 
+template <int P, int TC>
 __global__ void __launch_bounds__(256)
 k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int row0, int row1, int tiles_x,
-           int TR, int TC, int Dd, int shift, const int* __restrict__ doy_start,
-           const float* __restrict__ first_anom, const float* __restrict__ centres, int nb, double q, int wd,
-           int p, float lower_bound, float upper_bound, float* __restrict__ thr,
-           marex_thr_stats* __restrict__ stats) {
+           int Dd, int shift, const int* __restrict__ doy_start, const float* __restrict__ first_anom,
+           const float* __restrict__ centres, int nb, double q, int wd, float lower_bound, float upper_bound,
+           float* __restrict__ thr, marex_thr_stats* __restrict__ stats) {
+    constexpr int TR = 256 / TC;
+    constexpr int OR = TR - 2 * P, OC = TC - 2 * P;
     __shared__ unsigned lev[TB_NLP][256];
     __shared__ unsigned char gst[TB_DMAX][256];
     __shared__ int s_gmin, s_gmax;
 
     const int t = threadIdx.x;
     const int tr = t / TC, tc = t - tr * TC;
-    const int OR = TR - 2 * p, OC = TC - 2 * p;
     const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
     const int jt0 = row0 + ty * OR, it0 = tx * OC;
-    const int j = (ny > 0) ? jt0 - p + tr : 0;
-    const int icol = it0 - p + tc;
+    const int j = (ny > 0) ? jt0 - P + tr : 0;
+    const int icol = it0 - P + tc;
     bool cell_valid;
     long cell;
     if (ny > 0) {
@@ -748,14 +749,20 @@ k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int 
         cell_valid = icol < nx;
         cell = icol;
     }
-    const bool is_out = tr >= p && tr < TR - p && tc >= p && tc < TC - p && j < row1 && icol < nx;
+    const bool is_out = tr >= P && tr < TR - P && tc >= P && tc < TC - P && j < row1 && icol < nx;
     const int d_begin = (int)blockIdx.y * Dd;
     const int ndays = (NDOY - d_begin) < Dd ? (NDOY - d_begin) : Dd;
     const int pd = wd / 2;
     const int ngroups = ((nb - 1) >> shift) + 1;
+    const int gsz = 1 << shift;   // bins per coarse group
     const int gpp = 64 >> shift;  // groups per fine pass (>= 1): band of gpp << shift <= 64 bins
     bool land = true;
     if (is_out) land = !(first_anom[cell] == first_anom[cell]);
+    if (!__syncthreads_or(is_out && !land)) {  // nothing but land in this tile: all thresholds NaN
+        if (is_out)
+            for (int dd = 0; dd < ndays; ++dd) thr[(size_t)(d_begin + dd) * C + cell] = nan_f();
+        return;
+    }
 
     for (int r = 0; r < TB_NLP; ++r) lev[r][t] = 0u;
     if (t == 0) {
@@ -771,25 +778,44 @@ k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int 
         const int k = b - B0;
         return k < 0 ? 0 : (k >= BW ? BW + 1 : k + 1);
     };
-    // add (sgn=+1) / remove (sgn=-1) the bucket of dayofyear index d0 (0-based) of this lane's cell
-    auto add_bucket = [&](int d0, int sgn) {
-        const int r0 = doy_start[d0], nd = doy_start[d0 + 1] - r0;
-        const unsigned short* col = bins + (size_t)r0 * C + cell;
-        for (int r = 0; r < nd; r += 4) {
-            int bb[4];
+    const unsigned short* colbase = bins + cell;
+    // first TB_PRE samples of a dayofyear bucket of this lane's cell, kept in registers
+    struct Pre {
+        int b[TB_PRE];
+        int r0, nd;
+    };
+    auto load_bucket = [&](int d0) {
+        Pre pr;
+        pr.r0 = doy_start[d0];
+        pr.nd = cell_valid ? doy_start[d0 + 1] - pr.r0 : 0;  // lanes outside the grid never touch memory
+        const unsigned short* col = colbase + (size_t)pr.r0 * C;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) bb[u] = (r + u < nd) ? (int)col[(size_t)(r + u) * C] : nb;
+        for (int u = 0; u < TB_PRE; ++u) pr.b[u] = (u < pr.nd) ? (int)col[(size_t)u * C] : nb;
+        return pr;
+    };
+    auto bump = [&](int b, int sgn) {
+        if (b < nb) {
+            const int k = lvl(b);
+            atomicAdd(&lev[k >> 1][t], (unsigned)sgn * (1u << ((k & 1) * 16)));
+        }
+    };
+    auto apply_bucket = [&](const Pre& pr, int sgn) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (bb[u] < nb) {
-                    const int k = lvl(bb[u]);
-                    atomicAdd(&lev[k >> 1][t], (unsigned)sgn * (1u << ((k & 1) * 16)));
-                }
+        for (int u = 0; u < TB_PRE; ++u) bump(pr.b[u], sgn);
+        if (pr.nd > TB_PRE) {  // long buckets (many years): stream the rest, 4 loads in flight
+            const unsigned short* col = colbase + (size_t)pr.r0 * C;
+            for (int r = TB_PRE; r < pr.nd; r += 4) {
+                int bb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bb[u] = (r + u < pr.nd) ? (int)col[(size_t)(r + u) * C] : nb;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bump(bb[u], sgn);
             }
         }
     };
     auto prefix = [&](int nlp) {
         unsigned run = 0;
+#pragma unroll 4
         for (int r = 0; r < nlp; ++r) {
             const unsigned w = lev[r][t];
             const unsigned a = (w & 0xFFFFu) + run, b = (w >> 16) + a;
@@ -799,6 +825,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int 
     };
     auto unprefix = [&](int nlp) {
         unsigned prev = 0;
+#pragma unroll 4
         for (int r = 0; r < nlp; ++r) {
             const unsigned w = lev[r][t];
             const unsigned a = w & 0xFFFFu, b = w >> 16;
@@ -806,13 +833,15 @@ k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int 
             prev = b;
         }
     };
-    // pooled cumulative count at level k of this lane's (2p+1)^2 neighbourhood
+    // pooled cumulative count at level k of this lane's (2P+1)^2 neighbourhood (16-bit LDS reads)
+    const unsigned short* lev16 = reinterpret_cast<const unsigned short*>(&lev[0][0]);
     auto pooled = [&](int k) {
-        const unsigned* row = &lev[k >> 1][t];
-        const int sh16 = (k & 1) * 16;
+        const unsigned short* row = lev16 + ((size_t)(k >> 1) * 256 + t) * 2 + (k & 1);
         int s = 0;
-        for (int dr = -p; dr <= p; ++dr)
-            for (int dc = -p; dc <= p; ++dc) s += (int)((row[dr * TC + dc] >> sh16) & 0xFFFFu);
+#pragma unroll
+        for (int dr = -P; dr <= P; ++dr)
+#pragma unroll
+            for (int dc = -P; dc <= P; ++dc) s += (int)row[(dr * TC + dc) * 2];
         return s;
     };
     // smallest k in [klo, khi) with pooled(k) > qpos (khi if none).  With `counts`: ck = pooled(k) and
@@ -877,19 +906,28 @@ k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int 
         }
         const int nlp = (nlev + 1) >> 1;
         int hint = -1;
+        Pre pin, pout;  // entering / leaving bucket of the NEXT day, prefetched across the barrier
         for (int dd = 0; dd < ndays; ++dd) {
             const int d = d_begin + dd;
             // ---------------- P1: this lane's column
-            if (cell_valid) {
-                if (dd == 0) {
-                    for (int r = 0; r < nlp; ++r) lev[r][t] = 0u;
-                    for (int o = -pd; o <= pd; ++o) add_bucket(((d + o) % NDOY + NDOY) % NDOY, +1);
-                } else {
-                    unprefix(nlp);
-                    add_bucket((d + pd) % NDOY, +1);
-                    add_bucket(((d - pd - 1) % NDOY + NDOY) % NDOY, -1);
+            if (dd == 0) {
+                for (int r = 0; r < nlp; ++r) lev[r][t] = 0u;
+                Pre cur = load_bucket(((d - pd) % NDOY + NDOY) % NDOY);
+                for (int o = -pd + 1; o <= pd; ++o) {
+                    const Pre nxt = load_bucket(((d + o) % NDOY + NDOY) % NDOY);
+                    apply_bucket(cur, +1);
+                    cur = nxt;
                 }
-                prefix(nlp);
+                apply_bucket(cur, +1);
+            } else {
+                unprefix(nlp);
+                apply_bucket(pin, +1);
+                apply_bucket(pout, -1);
+            }
+            prefix(nlp);
+            if (dd + 1 < ndays) {
+                pin = load_bucket((d + 1 + pd) % NDOY);
+                pout = load_bucket(((d - pd) % NDOY + NDOY) % NDOY);
             }
             __syncthreads();
             // ---------------- P2: quantile level of this lane's output cell
@@ -915,10 +953,14 @@ k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int 
                     if (g != 255 && g >= g_base && g < g_base + gpp) {
                         const int tot = pooled(nlev - 1);
                         const double qpos = q * (double)tot;
+                        // the quantile bin lies inside group g: levels klo .. khi-1 of this band
+                        const int klo = ((g - g_base) << shift) + 1;
+                        int khi = klo + gsz;
+                        if (khi > BW + 1) khi = BW + 1;
                         int ck, cb;
-                        int k = find_level(hint, 1, BW + 1, qpos, true, ck, cb);
+                        int k = find_level(hint, klo, khi, qpos, true, ck, cb);
                         int iu = B0 + k - 1;
-                        if (k > BW) {  // no bin exceeds qpos (q == 1): searchsorted gives nb, clipped to nb-1
+                        if (k >= khi) {  // no bin exceeds qpos (q == 1): searchsorted gives nb, clipped to nb-1
                             iu = nb - 1;
                             k = iu - B0 + 1;
                             ck = pooled(k);
@@ -1001,23 +1043,30 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
 
     // ---- band algorithm (default) whenever its uint16 level counters and 64-bin bands suffice
     int shift = 0;
-    while ((((nb - 1) >> shift) + 1) > 64) ++shift;
-    const int algo = env_int("MAREX_THR_ALGO", 0);  // 0 auto, 1 force sliding histograms
-    const bool band_ok = (1 << shift) <= 64 && ws / 2 <= 6 && max_bucket > 0 && (int64_t)max_bucket * wd <= 65535;
+    while ((((nb - 1) >> shift) + 1) > 32) ++shift;  // at most 32 coarse groups
+    const int algo = env_int("MAREX_THR_ALGO", 0);   // 0 auto, 1 force sliding histograms
+    const int p = ws / 2;
+    const bool band_ok = (1 << shift) <= 64 && p <= 3 && max_bucket > 0 && (int64_t)max_bucket * wd <= 65535;
     if (algo != 1 && band_ok) {
-        const int p = ws / 2;
         const int TR = (ny > 0 && p > 0) ? 16 : 1, TC = 256 / TR;
         const int OR = TR - 2 * p, OC = TC - 2 * p;
         int Dd = env_int("MAREX_THR_DD", TB_DMAX);
         if (Dd < 1 || Dd > TB_DMAX) Dd = TB_DMAX;
         const int tiles_x = (nx + OC - 1) / OC, tiles_y = (row1 - row0 + OR - 1) / OR;
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((NDOY + Dd - 1) / Dd));
+#define MAREX_BAND_ARGS bins, (long)C, ny, nx, row0, row1, tiles_x, Dd, shift, doy_start, first_anom, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats
         {
             LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
-            hipLaunchKernelGGL(k_thr_band, grid, dim3(256), 0, ctx->stream, bins, (long)C, ny, nx, row0, row1,
-                               tiles_x, TR, TC, Dd, shift, doy_start, first_anom, centres, nb, q, wd, p,
-                               lower_bound, upper_bound, thr_doy_major, stats);
+            if (TR == 1)
+                hipLaunchKernelGGL((k_thr_band<0, 256>), grid, dim3(256), 0, ctx->stream, MAREX_BAND_ARGS);
+            else if (p == 1)
+                hipLaunchKernelGGL((k_thr_band<1, 16>), grid, dim3(256), 0, ctx->stream, MAREX_BAND_ARGS);
+            else if (p == 2)
+                hipLaunchKernelGGL((k_thr_band<2, 16>), grid, dim3(256), 0, ctx->stream, MAREX_BAND_ARGS);
+            else
+                hipLaunchKernelGGL((k_thr_band<3, 16>), grid, dim3(256), 0, ctx->stream, MAREX_BAND_ARGS);
         }
+#undef MAREX_BAND_ARGS
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     }
