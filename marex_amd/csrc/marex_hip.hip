@@ -717,20 +717,20 @@ k_thresholds(const unsigned short* __restrict__ bins, long C, int ny, int nx, in
 // of the 25-fold spatial fan-out that dominates the sliding-histogram kernel above.
 // ------------------------------------------------------------------------------------------------
 #define TB_NLP 33
-#define TB_DMAX 16
+#define TB_DMAX 32
 #define TB_PRE 8
 
 template <int P, int TC>
 __global__ void __launch_bounds__(256)
 k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int row0, int row1, int tiles_x,
-           int Dd, int shift, const int* __restrict__ doy_start, const float* __restrict__ first_anom,
-           const float* __restrict__ centres, int nb, double q, int wd, float lower_bound, float upper_bound,
-           float* __restrict__ thr, marex_thr_stats* __restrict__ stats) {
+           int Dd, int shift, int env_exact, const int* __restrict__ doy_start,
+           const float* __restrict__ first_anom, const float* __restrict__ centres, int nb, double q, int wd,
+           float lower_bound, float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats) {
     constexpr int TR = 256 / TC;
     constexpr int OR = TR - 2 * P, OC = TC - 2 * P;
     __shared__ unsigned lev[TB_NLP][256];
     __shared__ unsigned char gst[TB_DMAX][256];
-    __shared__ int s_gmin, s_gmax;
+    __shared__ int s_gmin, s_gmax, s_unres;
 
     const int t = threadIdx.x;
     const int tr = t / TC, tc = t - tr * TC;
@@ -768,6 +768,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int 
     if (t == 0) {
         s_gmin = 255;
         s_gmax = -1;
+        s_unres = env_exact;
     }
 
     // level mapping of the current pass
@@ -833,16 +834,16 @@ k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int 
             prev = b;
         }
     };
-    // pooled cumulative count at level k of this lane's (2P+1)^2 neighbourhood (16-bit LDS reads)
+    // pooled cumulative count at level k of this lane's (2P+1)^2 neighbourhood (unrolled 16-bit LDS reads)
     const unsigned short* lev16 = reinterpret_cast<const unsigned short*>(&lev[0][0]);
     auto pooled = [&](int k) {
         const unsigned short* row = lev16 + ((size_t)(k >> 1) * 256 + t) * 2 + (k & 1);
-        int s = 0;
+        int sum = 0;
 #pragma unroll
         for (int dr = -P; dr <= P; ++dr)
 #pragma unroll
-            for (int dc = -P; dc <= P; ++dc) s += (int)row[(dr * TC + dc) * 2];
-        return s;
+            for (int dc = -P; dc <= P; ++dc) sum += (int)row[(dr * TC + dc) * 2];
+        return sum;
     };
     // smallest k in [klo, khi) with pooled(k) > qpos (khi if none).  With `counts`: ck = pooled(k) and
     // cb = pooled(k-1) (0 for k == 0) on return.
@@ -892,22 +893,54 @@ k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int 
     };
 
     unsigned kmin = 0xFFFFFFFFu, kmax = 0u, nlow = 0u, nhigh = 0u;
-    int g_base = 0, g_last = -1;
-    for (int pass = 0;; ++pass) {
-        if (pass == 0) {
+    // gst[day][lane]: 255 = nothing (left) to do, 254 = quantile group unknown, 0..31 = coarse group known
+    for (int dd = 0; dd < ndays; ++dd) gst[dd][t] = (is_out && !land) ? 254 : 255;
+    if (is_out && land)
+        for (int dd = 0; dd < ndays; ++dd) thr[(size_t)(d_begin + dd) * C + cell] = nan_f();  // detect.py:2704
+    int g_base = 0;
+
+    // exact threshold of one output-day from level k of the current band (ck = cs[iu], cb = cs[iu-1])
+    auto emit_threshold = [&](int d, int iu, int ck, int cb, double qpos) {
+        const int il = iu > 0 ? iu - 1 : 0;
+        const int cs_iu = ck;
+        const int cs_il = iu > 0 ? cb : ck;
+        const int diff = cs_iu - cs_il;
+        const double frac = diff > 0 ? (qpos - (double)cs_il) / (double)diff : 0.5;
+        const float dc = centres[iu] - centres[il];
+        const double prod = frac * (double)dc;
+        float t32 = (float)((double)centres[il] + prod);
+        if (iu == 0) t32 = centres[0];
+        const unsigned key = ordered_key(t32);
+        kmin = key < kmin ? key : kmin;
+        kmax = key > kmax ? key : kmax;
+        if (t32 > upper_bound) ++nhigh;
+        if (t32 < lower_bound) {
+            ++nlow;
+            t32 = lower_bound;
+        }
+        thr[(size_t)d * C + cell] = t32;
+    };
+
+    // One sweep over the first nd_pass days of the block.
+    //   mode 0  coarse levels: group of the quantile bin for every output-day still marked 254
+    //   mode 1  fine levels, SPECULATIVE band (chosen from day 0): resolve what falls inside the band,
+    //           flag the rest (254) for the exact path
+    //   mode 2  fine levels, exact band g_base..: resolve the output-days whose group lies in the band
+    auto sweep = [&](int mode, int nd_pass, int ng) {
+        if (mode == 0) {
             fine = false;
             nlev = ngroups;
         } else {
             fine = true;
             B0 = g_base << shift;
-            BW = gpp << shift;
+            BW = ng << shift;
             if (B0 + BW > nb) BW = nb - B0;
             nlev = BW + 2;
         }
         const int nlp = (nlev + 1) >> 1;
         int hint = -1;
         Pre pin, pout;  // entering / leaving bucket of the NEXT day, prefetched across the barrier
-        for (int dd = 0; dd < ndays; ++dd) {
+        for (int dd = 0; dd < nd_pass; ++dd) {
             const int d = d_begin + dd;
             // ---------------- P1: this lane's column
             if (dd == 0) {
@@ -925,80 +958,112 @@ k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int 
                 apply_bucket(pout, -1);
             }
             prefix(nlp);
-            if (dd + 1 < ndays) {
+            if (dd + 1 < nd_pass) {
                 pin = load_bucket((d + 1 + pd) % NDOY);
                 pout = load_bucket(((d - pd) % NDOY + NDOY) % NDOY);
             }
             __syncthreads();
             // ---------------- P2: quantile level of this lane's output cell
-            if (is_out) {
-                if (pass == 0) {
-                    int g = 255;
-                    if (!land) {
-                        const int tot = pooled(nlev - 1);
-                        if (tot > 0) {
-                            int ck, cb;
-                            const double qpos = q * (double)tot;
-                            g = find_level(hint, 0, nlev, qpos, false, ck, cb);
-                            if (g >= nlev) g = nlev - 1;  // nothing above qpos: iu clips to nb-1
-                            hint = g;
-                            atomicMin(&s_gmin, g);
-                            atomicMax(&s_gmax, g);
-                        }
-                    }
-                    gst[dd][t] = (unsigned char)g;
-                    if (g == 255) thr[(size_t)d * C + cell] = nan_f();  // land or empty window
-                } else {
-                    const int g = gst[dd][t];
-                    if (g != 255 && g >= g_base && g < g_base + gpp) {
-                        const int tot = pooled(nlev - 1);
-                        const double qpos = q * (double)tot;
-                        // the quantile bin lies inside group g: levels klo .. khi-1 of this band
-                        const int klo = ((g - g_base) << shift) + 1;
-                        int khi = klo + gsz;
-                        if (khi > BW + 1) khi = BW + 1;
+            const int g = gst[dd][t];
+            if (mode == 0) {
+                if (g == 254) {
+                    const int tot = pooled(nlev - 1);
+                    if (tot > 0) {
                         int ck, cb;
-                        int k = find_level(hint, klo, khi, qpos, true, ck, cb);
-                        int iu = B0 + k - 1;
-                        if (k >= khi) {  // no bin exceeds qpos (q == 1): searchsorted gives nb, clipped to nb-1
-                            iu = nb - 1;
-                            k = iu - B0 + 1;
-                            ck = pooled(k);
-                            cb = pooled(k - 1);
-                        }
-                        hint = k;
-                        const int il = iu > 0 ? iu - 1 : 0;
-                        const int cs_iu = ck;
-                        const int cs_il = iu > 0 ? cb : ck;
-                        const int diff = cs_iu - cs_il;
-                        const double frac = diff > 0 ? (qpos - (double)cs_il) / (double)diff : 0.5;
-                        const float dc = centres[iu] - centres[il];
-                        const double prod = frac * (double)dc;
-                        float t32 = (float)((double)centres[il] + prod);
-                        if (iu == 0) t32 = centres[0];
-                        const unsigned key = ordered_key(t32);
-                        kmin = key < kmin ? key : kmin;
-                        kmax = key > kmax ? key : kmax;
-                        if (t32 > upper_bound) ++nhigh;
-                        if (t32 < lower_bound) {
-                            ++nlow;
-                            t32 = lower_bound;
-                        }
-                        thr[(size_t)d * C + cell] = t32;
+                        int gg = find_level(hint, 0, nlev, q * (double)tot, false, ck, cb);
+                        if (gg >= nlev) gg = nlev - 1;  // nothing above qpos: iu clips to nb-1
+                        hint = gg;
+                        gst[dd][t] = (unsigned char)gg;
+                        atomicMin(&s_gmin, gg);
+                        atomicMax(&s_gmax, gg);
                     } else {
-                        hint = -1;
+                        gst[dd][t] = 255;
+                        thr[(size_t)d * C + cell] = nan_f();  // empty window
                     }
+                }
+            } else if (mode == 1) {
+                if (g != 255) {
+                    const int tot = pooled(nlev - 1);
+                    if (tot > 0) {
+                        const double qpos = q * (double)tot;
+                        if (hint < 0 && g < 254) hint = ((g - g_base) << shift) + 1 + (gsz >> 1);
+                        int ck, cb;
+                        const int k = find_level(hint, 1, BW + 1, qpos, true, ck, cb);
+                        // inside the band iff cs[B0-1] <= qpos (k == 1 needs the check) and some band bin exceeds qpos
+                        const bool ok = (k <= BW) && (k > 1 || !((double)cb > qpos));
+                        if (ok) {
+                            hint = k;
+                            emit_threshold(d, B0 + k - 1, ck, cb, qpos);
+                            gst[dd][t] = 255;
+                        } else {
+                            hint = -1;
+                            gst[dd][t] = 254;
+                            s_unres = 1;
+                        }
+                    } else {
+                        gst[dd][t] = 255;
+                        thr[(size_t)d * C + cell] = nan_f();
+                    }
+                }
+            } else {
+                if (g < 254 && g >= g_base && g < g_base + ng) {
+                    const int tot = pooled(nlev - 1);
+                    const double qpos = q * (double)tot;
+                    // the quantile bin lies inside group g: levels klo .. khi-1 of this band
+                    const int klo = ((g - g_base) << shift) + 1;
+                    int khi = klo + gsz;
+                    if (khi > BW + 1) khi = BW + 1;
+                    int ck, cb;
+                    int k = find_level(hint, klo, khi, qpos, true, ck, cb);
+                    int iu = B0 + k - 1;
+                    if (k >= khi) {  // no bin exceeds qpos (q == 1): searchsorted gives nb, clipped to nb-1
+                        iu = nb - 1;
+                        k = iu - B0 + 1;
+                        ck = pooled(k);
+                        cb = pooled(k - 1);
+                    }
+                    hint = k;
+                    emit_threshold(d, iu, ck, cb, qpos);
+                    gst[dd][t] = 255;
+                } else {
+                    hint = -1;
                 }
             }
             __syncthreads();
         }
-        if (pass == 0) {
-            g_base = s_gmin;
-            g_last = s_gmax;
-        } else {
-            g_base += gpp;
+    };
+
+    __syncthreads();
+    sweep(0, 1, 0);  // coarse, day 0 only
+    int gmin = s_gmin, gmax = s_gmax;
+    __syncthreads();
+    if (!env_exact && gmax >= 0 && gmax - gmin + 1 <= gpp) {
+        // speculative band of gpp groups placed around what day 0 needs (room for drift on both sides)
+        const int spare = gpp - (gmax - gmin + 1);
+        g_base = gmin - (spare + 1) / 2;
+        if (g_base < 0) g_base = 0;
+        if (g_base + gpp > ngroups) g_base = ngroups - gpp > 0 ? ngroups - gpp : 0;
+        sweep(1, ndays, gpp < ngroups ? gpp : ngroups);
+    } else if (t == 0) {
+        s_unres = 1;
+    }
+    __syncthreads();
+    if (s_unres) {  // exact path for whatever is not resolved yet
+        for (int dd = 0; dd < ndays; ++dd)
+            if (gst[dd][t] < 254) gst[dd][t] = 254;  // day-0 groups of a skipped speculative sweep: redo
+        __syncthreads();
+        if (t == 0) {
+            s_gmin = 255;
+            s_gmax = -1;
         }
-        if (g_base > g_last) break;  // also: nothing but land / empty windows in this tile
+        __syncthreads();
+        sweep(0, ndays, 0);
+        gmin = s_gmin;
+        gmax = s_gmax;
+        for (g_base = gmin; g_base <= gmax; g_base += gpp) {
+            const int ng = (gmax - g_base + 1) < gpp ? (gmax - g_base + 1) : gpp;
+            sweep(2, ndays, ng);
+        }
     }
     // statistics: wave reduction, one set of global atomics per wave
     for (int sft = 32; sft > 0; sft >>= 1) {
@@ -1054,7 +1119,7 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
         if (Dd < 1 || Dd > TB_DMAX) Dd = TB_DMAX;
         const int tiles_x = (nx + OC - 1) / OC, tiles_y = (row1 - row0 + OR - 1) / OR;
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((NDOY + Dd - 1) / Dd));
-#define MAREX_BAND_ARGS bins, (long)C, ny, nx, row0, row1, tiles_x, Dd, shift, doy_start, first_anom, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats
+#define MAREX_BAND_ARGS bins, (long)C, ny, nx, row0, row1, tiles_x, Dd, shift, env_int("MAREX_THR_EXACT_PATH", 0), doy_start, first_anom, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats
         {
             LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
             if (TR == 1)

@@ -51,6 +51,18 @@ class HotPath:
         self._tables: Dict[int, tuple] = {}
         self._bind_stream()
 
+    @staticmethod
+    def _buf(wsp: Optional[dict], name: str, shape, dtype, device) -> torch.Tensor:
+        """Output buffer: fresh when ``wsp`` is None, otherwise cached in the workspace dict and reused
+        (no allocator traffic in the steady state, outputs of the previous call are overwritten)."""
+        if wsp is None:
+            return torch.empty(shape, dtype=dtype, device=device)
+        t = wsp.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            wsp[name] = t
+        return t
+
     # ------------------------------------------------------------------ plumbing
     def _bind_stream(self) -> None:
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
@@ -106,6 +118,7 @@ class HotPath:
         S: int,
         bins: Optional[BinTable] = None,
         write_clim: bool = False,
+        wsp: Optional[dict] = None,
     ) -> Dict[str, torch.Tensor]:
         self._bind_stream()
         assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
@@ -119,14 +132,15 @@ class HotPath:
                 details="sub-daily time axes are not supported by the device path",
             )
         T_out = cal.T_out
-        out = torch.empty((T_out, Cn), dtype=torch.float32, device=self.device)
+        out = self._buf(wsp, "anom", (T_out, Cn), torch.float32, self.device)
         if write_clim:
             out.fill_(float("nan"))
-        mask = torch.empty((Cn,), dtype=torch.uint8, device=self.device)
-        invalid = torch.zeros((Cn,), dtype=torch.int32, device=self.device)
+        mask = self._buf(wsp, "mask", (Cn,), torch.uint8, self.device)
+        invalid = self._buf(wsp, "invalid", (Cn,), torch.int32, self.device)
+        invalid.zero_()
         if bins is not None and not write_clim:
             edges = self.bin_tables(bins)[0]
-            binsb = torch.empty((T_out, Cn), dtype=torch.int16, device=self.device)
+            binsb = self._buf(wsp, "bins", (T_out, Cn), torch.int16, self.device)
             e_ptr, b_ptr, nb = edges.data_ptr(), binsb.data_ptr(), bins.nb
         else:
             edges = binsb = None
@@ -155,13 +169,15 @@ class HotPath:
         ny: int,
         nx: int,
         rows: Optional[tuple] = None,
+        wsp: Optional[dict] = None,
     ) -> Dict[str, object]:
         """``rows=(row0, row1)`` restricts the output to the grid rows a latitude shard owns."""
         self._bind_stream()
         T_out, Cn = binsb.shape
         row0, row1 = rows if rows is not None else (0, max(ny, 1))
-        thr = torch.empty((N_DOY, Cn), dtype=torch.float32, device=self.device)
-        stats = torch.zeros((4,), dtype=torch.int32, device=self.device)
+        thr = self._buf(wsp, "thr_doy_major", (N_DOY, Cn), torch.float32, self.device)
+        stats = self._buf(wsp, "thr_stats", (4,), torch.int32, self.device)
+        stats.zero_()
         stats[0] = -1  # min_key = 0xFFFFFFFF
         centres = self.bin_tables(bins)[1]
         rc = self.lib.marex_hobday_thresholds_f32(
@@ -185,14 +201,16 @@ class HotPath:
 
     # ------------------------------------------------------------------ stage a9 compare
     def mask_ge_doy(
-        self, anom: torch.Tensor, thr_doy_major: torch.Tensor, dcal: DeviceCalendar, cells: Optional[tuple] = None
+        self, anom: torch.Tensor, thr_doy_major: torch.Tensor, dcal: DeviceCalendar, cells: Optional[tuple] = None,
+        wsp: Optional[dict] = None,
     ) -> Dict[str, torch.Tensor]:
         """``cells=(c0, c1)`` restricts compare / write / count to the owned cells of a shard."""
         self._bind_stream()
         T_out, Cn = anom.shape
         c0, c1 = cells if cells is not None else (0, Cn)
-        ext = torch.empty((T_out, Cn), dtype=torch.uint8, device=self.device)
-        n_true = torch.zeros((1,), dtype=torch.int64, device=self.device)
+        ext = self._buf(wsp, "extreme", (T_out, Cn), torch.uint8, self.device)
+        n_true = self._buf(wsp, "n_true", (1,), torch.int64, self.device)
+        n_true.zero_()
         rc = self.lib.marex_mask_ge_doy_f32(
             self.ctx.handle, anom.data_ptr(), thr_doy_major.data_ptr(), dcal.doy_start.data_ptr(),
             dcal.doy_rows.data_ptr(), T_out, Cn, int(c0), int(c1), ext.data_ptr(), n_true.data_ptr(),
@@ -200,10 +218,10 @@ class HotPath:
         self.ctx.check(rc, "marex_mask_ge_doy_f32")
         return {"extreme": ext, "n_true": n_true}
 
-    def transpose(self, a: torch.Tensor) -> torch.Tensor:
+    def transpose(self, a: torch.Tensor, wsp: Optional[dict] = None, name: str = "transposed") -> torch.Tensor:
         self._bind_stream()
         rows, cols = a.shape
-        out = torch.empty((cols, rows), dtype=torch.float32, device=self.device)
+        out = self._buf(wsp, name, (cols, rows), torch.float32, self.device)
         self.ctx.check(self.lib.marex_transpose_f32(self.ctx.handle, a.data_ptr(), rows, cols, out.data_ptr()), "marex_transpose_f32")
         return out
 
@@ -223,16 +241,17 @@ class HotPath:
         nx: int,
         transpose_thresholds: bool = True,
         own_rows: Optional[tuple] = None,
+        workspace: Optional[dict] = None,
     ) -> Dict[str, object]:
         """validation + anomaly + thresholds + mask for ``shifting_baseline`` / ``hobday_extreme`` (approximate).
 
         ``own_rows=(row0, row1)``: the field is a latitude shard with overlap rows; thresholds and the
         mask are produced for the owned rows only (:mod:`marex_amd.dist`).
         """
-        a = self.shifting_baseline(x, dcal, W, S, bins)
+        a = self.shifting_baseline(x, dcal, W, S, bins, wsp=workspace)
         cells = None if own_rows is None else (own_rows[0] * nx, own_rows[1] * nx)
-        t = self.hobday_thresholds(a["bins"], a["out"], dcal, bins, q, wd, ws, ny, nx, rows=own_rows)
-        m = self.mask_ge_doy(a["out"], t["thr_doy_major"], dcal, cells=cells)
+        t = self.hobday_thresholds(a["bins"], a["out"], dcal, bins, q, wd, ws, ny, nx, rows=own_rows, wsp=workspace)
+        m = self.mask_ge_doy(a["out"], t["thr_doy_major"], dcal, cells=cells, wsp=workspace)
         res = {
             "dat_anomaly": a["out"],
             "mask": a["mask"],
@@ -244,7 +263,7 @@ class HotPath:
             "_keep": (a["_keep"], t["_keep"], a.get("bins")),
         }
         if transpose_thresholds:
-            res["thresholds"] = self.transpose(t["thr_doy_major"])
+            res["thresholds"] = self.transpose(t["thr_doy_major"], wsp=workspace, name="thresholds")
         return res
 
     # ------------------------------------------------------------------ stages not on the device yet

@@ -33,3 +33,13 @@ def test_bad_context_is_an_error_code_not_a_crash():
     lib = _lib.load()
     assert lib.marex_sync(None) != 0
     assert lib.marex_destroy(None) != 0
+
+
+def test_host_modules_import_without_gpu():
+    """engine / detect / dist import cleanly on a CPU-only box (the GPU is touched at first compute call)."""
+    import marex_amd
+    import marex_amd.detect
+    import marex_amd.dist
+    import marex_amd.engine  # noqa: F401
+
+    assert callable(marex_amd.preprocess_data)

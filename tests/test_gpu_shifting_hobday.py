@@ -116,7 +116,7 @@ def test_threshold_kernel_variants(hot, monkeypatch):
     """Band algorithm with other day-block lengths and the sliding-histogram kernel (16/32-bit counters,
     other segment widths) all give the same bits as the default."""
     envs = (
-        {"MAREX_THR_DD": "1"}, {"MAREX_THR_DD": "5"},
+        {"MAREX_THR_DD": "1"}, {"MAREX_THR_DD": "5"}, {"MAREX_THR_DD": "32"}, {"MAREX_THR_EXACT_PATH": "1"},
         {"MAREX_THR_ALGO": "1"}, {"MAREX_THR_ALGO": "1", "MAREX_THR_U32": "1"},
         {"MAREX_THR_ALGO": "1", "MAREX_THR_NW": "5"}, {"MAREX_THR_ALGO": "1", "MAREX_THR_NW": "64", "MAREX_THR_U32": "1"},
     )
