@@ -127,6 +127,31 @@ int marex_mask_ge_doy_f32(marex_ctx* ctx, const float* anom, const float* thr_do
                           const int32_t* doy_start, const int32_t* doy_rows, int64_t T_out, int64_t C,
                           int64_t c0, int64_t c1, uint8_t* extreme, unsigned long long* n_true);
 
+/*
+ * Fixed-baseline anomaly (detect.py:2299-2397): clim[d, c] = float32 nanmean of x over the timesteps with
+ * dayofyear d (only those with use_row[t] != 0 when use_row is given: reference_period, 2334-2361),
+ * out[t, c] = x[t, c] - clim[doy(t), c] for ALL timesteps.  doy_start / doy_rows describe all T rows
+ * (calendar built without trim).  bins / mask / invalid_count as in marex_shifting_baseline_f32
+ * (bins rows are the dayofyear-sorted rows; invalid_count must be zeroed by the caller).
+ */
+int marex_fixed_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* doy_start,
+                             const int32_t* doy_rows, const uint8_t* use_row, const float* edges, int nb,
+                             float* out, uint16_t* bins, uint8_t* mask, int32_t* invalid_count);
+
+/* bins[rowb_index[t], c] = np.digitize(anom[t, c], edges) - 1 for rows with rowb_index[t] >= 0 (detect.py:2622-2631) */
+int marex_digitize_f32(marex_ctx* ctx, const float* anom, int64_t T, int64_t C, const int32_t* rowb_index,
+                       const float* edges, int nb, uint16_t* bins);
+
+/*
+ * Polynomial / harmonic detrend (detect.py:2143-2224).  pmodel[T, n_coef] = pinv(model) and
+ * model_t[T, n_coef] = model^T, float64, computed on the host (marex_amd/calendar.py:detrend_model).
+ * out = x - fl32(model^T (pmodel^T x)), minus its time mean when force_zero_mean.  mask / invalid_count
+ * are written (not accumulated) when given.
+ */
+int marex_detrend_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
+                      const double* model_t, int n_coef, int force_zero_mean, float* out, uint8_t* mask,
+                      int32_t* invalid_count);
+
 /* out[c, r] = in[r, c]  (thresholds [366, C] -> the reference's (cells, dayofyear) order) */
 int marex_transpose_f32(marex_ctx* ctx, const float* in, int64_t rows, int64_t cols, float* out);
 

@@ -44,6 +44,9 @@ PROTOTYPES = {
     ),
     "marex_mask_ge_doy_f32": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "marex_transpose_f32": (_i32, [_p, _p, _i64, _i64, _p]),
+    "marex_fixed_baseline_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
+    "marex_digitize_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _p]),
+    "marex_detrend_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
 }
 
 KERNEL_IDS = {

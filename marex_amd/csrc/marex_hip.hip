@@ -1257,6 +1257,176 @@ extern "C" int marex_mask_ge_doy_f32(marex_ctx* ctx, const float* anom, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// K_F: fixed-baseline anomaly (detect.py:2299-2397).  Work item = (256 cells, one dayofyear): the
+// float32 nanmean of all timesteps of that dayofyear (optionally only reference-period years) in
+// ascending time, then anom = x - clim for the same rows (second read comes from L2).  Also emits the
+// dayofyear-sorted bins, the t=0 mask and the validation counts like the shifting-baseline kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_fixed_baseline(const float* __restrict__ x, long T, long C, const int* __restrict__ doy_start,
+                 const int* __restrict__ doy_rows, const unsigned char* __restrict__ use_row,
+                 const float* __restrict__ edges, int nb, float* __restrict__ out,
+                 unsigned short* __restrict__ bins, unsigned char* __restrict__ mask,
+                 int* __restrict__ invalid_count) {
+    extern __shared__ float e[];
+    const int d = blockIdx.y;
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool do_bins = bins != nullptr;
+    if (do_bins) {
+        for (int i = threadIdx.x; i <= nb; i += 256) e[i] = edges[i];
+        __syncthreads();
+    }
+    if (c >= C) return;
+    const float inv_width = do_bins ? (float)(nb - 1) / (e[nb] - e[1]) : 0.f;
+    if (d == 0 && mask) mask[c] = finite_f(x[c]) ? 1 : 0;
+    const int r0 = doy_start[d], r1 = doy_start[d + 1];
+    float acc = 0.f;
+    int n = 0, n_invalid = 0;
+    for (int r = r0; r < r1; ++r) {
+        const int t = doy_rows[r];
+        const float v = x[(size_t)t * C + c];
+        if (!finite_f(v)) ++n_invalid;
+        if ((!use_row || use_row[t]) && v == v) {
+            acc += v;
+            ++n;
+        }
+    }
+    const float clim = acc / (float)n;  // n == 0 -> NaN
+    for (int r = r0; r < r1; ++r) {
+        const int t = doy_rows[r];
+        const float a = x[(size_t)t * C + c] - clim;
+        out[(size_t)t * C + c] = a;
+        if (do_bins) bins[(size_t)r * C + c] = (unsigned short)digitize_bin(a, e, nb, inv_width);
+    }
+    if (invalid_count && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
+}
+
+extern "C" int marex_fixed_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
+                                        const int32_t* doy_start, const int32_t* doy_rows,
+                                        const uint8_t* use_row, const float* edges, int nb, float* out,
+                                        uint16_t* bins, uint8_t* mask, int32_t* invalid_count) {
+    if (!ctx) return -1;
+    if (!x || !doy_start || !doy_rows || !out || T <= 0 || C <= 0)
+        return fail(ctx, -1, "marex_fixed_baseline_f32: null pointer or empty shape");
+    if (bins && (!edges || nb < 4 || nb > 36000)) return fail(ctx, -1, "marex_fixed_baseline_f32: binning needs edges and 4 <= nb <= 36000");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((C + 255) / 256), NDOY);
+    const size_t lds = bins ? ((size_t)nb + 1) * sizeof(float) : 0;
+    if (lds > 48 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_fixed_baseline, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        LaunchTimer lt(ctx, MAREX_K_FIXED);
+        hipLaunchKernelGGL(k_fixed_baseline, grid, dim3(256), lds, ctx->stream, x, (long)T, (long)C, doy_start, doy_rows,
+                           use_row, edges, nb, out, bins, mask, invalid_count);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone binning of an anomaly field into the dayofyear-sorted bin matrix (detect.py:2622-2631)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_digitize(const float* __restrict__ anom, long T, long C, const int* __restrict__ rowb_index,
+           const float* __restrict__ edges, int nb, int rows_per_block, unsigned short* __restrict__ bins) {
+    extern __shared__ float e[];
+    for (int i = threadIdx.x; i <= nb; i += 256) e[i] = edges[i];
+    __syncthreads();
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float inv_width = (float)(nb - 1) / (e[nb] - e[1]);
+    const long t0 = (long)blockIdx.y * rows_per_block;
+    const long t1 = t0 + rows_per_block < T ? t0 + rows_per_block : T;
+    for (long t = t0; t < t1; ++t) {
+        const int rb = rowb_index[t];
+        if (rb >= 0) bins[(size_t)rb * C + c] = (unsigned short)digitize_bin(anom[(size_t)t * C + c], e, nb, inv_width);
+    }
+}
+
+extern "C" int marex_digitize_f32(marex_ctx* ctx, const float* anom, int64_t T, int64_t C, const int32_t* rowb_index,
+                                  const float* edges, int nb, uint16_t* bins) {
+    if (!ctx) return -1;
+    if (!anom || !rowb_index || !edges || !bins || T <= 0 || C <= 0 || nb < 4 || nb > 36000)
+        return fail(ctx, -1, "marex_digitize_f32: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rows = 32;
+    dim3 grid((unsigned)((C + 255) / 256), (unsigned)((T + rows - 1) / rows));
+    const size_t lds = ((size_t)nb + 1) * sizeof(float);
+    if (lds > 48 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_digitize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        LaunchTimer lt(ctx, MAREX_K_FIXED);
+        hipLaunchKernelGGL(k_digitize, grid, dim3(256), lds, ctx->stream, anom, (long)T, (long)C, rowb_index, edges, nb,
+                           rows, bins);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_D: polynomial / harmonic detrend (detect.py:2143-2224).  One lane per cell streams its series:
+//   pass 1  coef[k] = sum_t pmodel[t][k] * x[t]      (float64, ascending t, separately rounded mul/add)
+//   pass 2  resid[t] = x[t] - fl32( sum_k model[k][t] * coef[k] )   and the float64 sum of resid
+//   pass 3  (force_zero_mean) resid[t] -= fl32( sum / T )
+// n_coef <= 8 (1 + polynomial orders + 4 harmonics): 4 flop per byte, far below any MFMA use.
+// The model tables are tiny ([T, n_coef] float64) and read through the scalar cache (uniform address).
+// ------------------------------------------------------------------------------------------------
+#define DETREND_MAXC 12
+__global__ void __launch_bounds__(256)
+k_detrend(const float* __restrict__ x, long T, long C, const double* __restrict__ pmodel /*[T][n]*/,
+          const double* __restrict__ model_t /*[T][n]*/, int n_coef, int force_zero_mean, float* __restrict__ out,
+          unsigned char* __restrict__ mask, int* __restrict__ invalid_count) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double coef[DETREND_MAXC];
+#pragma unroll
+    for (int k = 0; k < DETREND_MAXC; ++k) coef[k] = 0.0;
+    int n_invalid = 0;
+    for (long t = 0; t < T; ++t) {
+        const float v = x[(size_t)t * C + c];
+        if (!finite_f(v)) ++n_invalid;
+        const double vd = (double)v;
+        const double* pm = pmodel + (size_t)t * n_coef;
+#pragma unroll
+        for (int k = 0; k < DETREND_MAXC; ++k)
+            if (k < n_coef) coef[k] += pm[k] * vd;
+    }
+    if (mask) mask[c] = finite_f(x[c]) ? 1 : 0;
+    if (invalid_count) invalid_count[c] = n_invalid;
+    double sum = 0.0;
+    for (long t = 0; t < T; ++t) {
+        const double* mt = model_t + (size_t)t * n_coef;
+        double trend = 0.0;
+#pragma unroll
+        for (int k = 0; k < DETREND_MAXC; ++k)
+            if (k < n_coef) trend += mt[k] * coef[k];
+        const float r = x[(size_t)t * C + c] - (float)trend;
+        out[(size_t)t * C + c] = r;
+        sum += (double)r;
+    }
+    if (force_zero_mean) {
+        const float mean = (float)(sum / (double)T);
+        for (long t = 0; t < T; ++t) out[(size_t)t * C + c] -= mean;
+    }
+}
+
+extern "C" int marex_detrend_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
+                                 const double* model_t, int n_coef, int force_zero_mean, float* out, uint8_t* mask,
+                                 int32_t* invalid_count) {
+    if (!ctx) return -1;
+    if (!x || !pmodel || !model_t || !out || T <= 0 || C <= 0) return fail(ctx, -1, "marex_detrend_f32: null pointer or empty shape");
+    if (n_coef < 1 || n_coef > DETREND_MAXC) return fail(ctx, -4, "marex_detrend_f32: n_coef must be in 1..%d", DETREND_MAXC);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        LaunchTimer lt(ctx, MAREX_K_DETREND);
+        hipLaunchKernelGGL(k_detrend, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, ctx->stream, x, (long)T, (long)C,
+                           pmodel, model_t, n_coef, force_zero_mean, out, mask, invalid_count);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // transpose (thresholds [366, C] -> [C, 366])
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ in, long rows, long cols,

@@ -266,15 +266,94 @@ class HotPath:
             res["thresholds"] = self.transpose(t["thr_doy_major"], wsp=workspace, name="thresholds")
         return res
 
+    # ------------------------------------------------------------------ stage a13 (fixed baseline)
+    def fixed_baseline(
+        self,
+        x: torch.Tensor,
+        dcal: DeviceCalendar,
+        reference_period=None,
+        bins: Optional[BinTable] = None,
+        count_invalid: bool = True,
+        wsp: Optional[dict] = None,
+    ) -> Dict[str, torch.Tensor]:
+        """``x - nanmean_doy(x)`` for all timesteps (detect.py:2299-2397); ``dcal`` must be an untrimmed calendar."""
+        self._bind_stream()
+        T, Cn = x.shape
+        cal = dcal.plan
+        assert cal.T == T and cal.T_out == T, "fixed_baseline needs an untrimmed calendar"
+        use = None
+        if reference_period is not None:
+            use = self._dev(((cal.year >= reference_period[0]) & (cal.year <= reference_period[1])).astype(np.uint8))
+        out = self._buf(wsp, "anom", (T, Cn), torch.float32, self.device)
+        mask = self._buf(wsp, "mask", (Cn,), torch.uint8, self.device)
+        invalid = self._buf(wsp, "invalid", (Cn,), torch.int32, self.device)
+        invalid.zero_()
+        if bins is not None:
+            edges = self.bin_tables(bins)[0]
+            binsb = self._buf(wsp, "bins", (T, Cn), torch.int16, self.device)
+            e_ptr, b_ptr, nb = edges.data_ptr(), binsb.data_ptr(), bins.nb
+        else:
+            binsb, e_ptr, b_ptr, nb = None, None, None, 0
+        rc = self.lib.marex_fixed_baseline_f32(
+            self.ctx.handle, x.data_ptr(), T, Cn, dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(),
+            use.data_ptr() if use is not None else None, e_ptr, nb, out.data_ptr(), b_ptr,
+            mask.data_ptr(), invalid.data_ptr() if count_invalid else None,
+        )
+        self.ctx.check(rc, "marex_fixed_baseline_f32")
+        if use is not None:
+            self.sync()  # the small table must outlive the kernel
+        res = {"out": out, "mask": mask, "invalid_count": invalid}
+        if binsb is not None:
+            res["bins"] = binsb
+        return res
+
+    # ------------------------------------------------------------------ stage a10 binning on its own
+    def digitize(self, anom: torch.Tensor, dcal: DeviceCalendar, bins: BinTable, wsp: Optional[dict] = None) -> torch.Tensor:
+        """Dayofyear-sorted bin matrix of an anomaly field (rows with ``rowb_index < 0`` are skipped)."""
+        self._bind_stream()
+        T, Cn = anom.shape
+        edges = self.bin_tables(bins)[0]
+        binsb = self._buf(wsp, "bins", (dcal.plan.T_out, Cn), torch.int16, self.device)
+        rc = self.lib.marex_digitize_f32(
+            self.ctx.handle, anom.data_ptr(), T, Cn, dcal.rowb_index.data_ptr(), edges.data_ptr(), bins.nb, binsb.data_ptr()
+        )
+        self.ctx.check(rc, "marex_digitize_f32")
+        return binsb
+
+    # ------------------------------------------------------------------ stage a12 (detrend)
+    def detrend(
+        self,
+        x: torch.Tensor,
+        model: np.ndarray,
+        pmodel: np.ndarray,
+        force_zero_mean: bool,
+        bins_and_cal=None,
+        count_invalid: bool = True,
+        wsp: Optional[dict] = None,
+    ) -> Dict[str, torch.Tensor]:
+        """Residual of the least-squares fit of ``model`` (detect.py:2143-2224); optional binning of the result."""
+        self._bind_stream()
+        T, Cn = x.shape
+        n_coef = int(model.shape[0])
+        pm = self._dev(np.ascontiguousarray(pmodel, dtype=np.float64))
+        mt = self._dev(np.ascontiguousarray(model.T, dtype=np.float64))
+        out = self._buf(wsp, "detrended", (T, Cn), torch.float32, self.device)
+        mask = self._buf(wsp, "mask", (Cn,), torch.uint8, self.device)
+        invalid = self._buf(wsp, "invalid", (Cn,), torch.int32, self.device)
+        rc = self.lib.marex_detrend_f32(
+            self.ctx.handle, x.data_ptr(), T, Cn, pm.data_ptr(), mt.data_ptr(), n_coef, int(bool(force_zero_mean)),
+            out.data_ptr(), mask.data_ptr(), invalid.data_ptr(),
+        )
+        self.ctx.check(rc, "marex_detrend_f32")
+        self.sync()  # pm / mt must outlive the kernel
+        res = {"out": out, "mask": mask, "invalid_count": invalid}
+        if bins_and_cal is not None and bins_and_cal[0] is not None:
+            res["bins"] = self.digitize(out, bins_and_cal[1], bins_and_cal[0], wsp=wsp)
+        return res
+
     # ------------------------------------------------------------------ stages not on the device yet
     def _todo(self, what: str):
         raise ProcessingError(f"{what} is not implemented on the device path yet")
-
-    def fixed_baseline(self, x, dcal, reference_period, bins, count_invalid=True):
-        self._todo("fixed_baseline anomaly")
-
-    def detrend(self, x, model, pmodel, force_zero_mean, bins_and_cal, count_invalid=True):
-        self._todo("polynomial / harmonic detrend")
 
     def hobday_thresholds_exact(self, anom, dcal, percentile, wd):
         self._todo("exact Hobday percentile")
@@ -284,6 +363,3 @@ class HotPath:
 
     def mask_ge_const(self, anom, thr):
         self._todo("constant-threshold mask")
-
-    def digitize(self, anom, dcal, bins):
-        self._todo("stand-alone binning")
