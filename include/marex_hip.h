@@ -152,6 +152,32 @@ int marex_detrend_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, cons
                       const double* model_t, int n_coef, int force_zero_mean, float* out, uint8_t* mask,
                       int32_t* invalid_count);
 
+/*
+ * Exact Hobday percentile (detect.py:1921-1956): thr[d, c] = np.nanpercentile(anom[doy in window(d), c], p),
+ * float32, NumPy 2.x "linear" rule, no spatial pooling; output layout [366, C] (= the reference's
+ * (dayofyear, space) order for this method).  q32 = float32(p) / float32(100) computed by the caller with
+ * NumPy; max_window_rows = largest number of rows in any wd-day window; *overflow (device int, zeroed by
+ * the caller) counts cells whose selection buffer was too small (must stay 0).
+ */
+int marex_hobday_exact_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
+                           const int32_t* doy_rows, int max_window_rows, float q32, double q, int wd,
+                           float* thr_doy_major, int32_t* overflow);
+
+/*
+ * Global (constant-in-time) threshold per cell (detect.py:2873-2912).
+ *  exact != 0 : float64 np.nanquantile(anom[:, c], q) ("linear"), edges/centres/stats/minmax unused.
+ *  exact == 0 : _compute_histogram_quantile_1d (2737-2865) on float64 edges[nb+1] / centres[nb]; thresholds
+ *               below lower_bound are clamped; stats counts the out-of-range thresholds and minmax[2]
+ *               (device, initialised {+inf, -inf}) receives the un-clamped extremes for the warning text.
+ */
+int marex_global_threshold_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, double q, int exact,
+                               const double* edges, const double* centres, int nb, double lower_bound,
+                               double upper_bound, double* thr, marex_thr_stats* stats, double* minmax);
+
+/* extreme[t, c] = anom[t, c] >= thr[c] (comparison in float64, detect.py:2915) and the count of True */
+int marex_mask_ge_const_f32(marex_ctx* ctx, const float* anom, const double* thr, int64_t T_out, int64_t C,
+                            uint8_t* extreme, unsigned long long* n_true);
+
 /* out[c, r] = in[r, c]  (thresholds [366, C] -> the reference's (cells, dayofyear) order) */
 int marex_transpose_f32(marex_ctx* ctx, const float* in, int64_t rows, int64_t cols, float* out);
 

@@ -351,15 +351,73 @@ class HotPath:
             res["bins"] = self.digitize(out, bins_and_cal[1], bins_and_cal[0], wsp=wsp)
         return res
 
-    # ------------------------------------------------------------------ stages not on the device yet
-    def _todo(self, what: str):
-        raise ProcessingError(f"{what} is not implemented on the device path yet")
+    # ------------------------------------------------------------------ stage a9 exact Hobday
+    def hobday_thresholds_exact(self, anom: torch.Tensor, dcal: DeviceCalendar, percentile: float, wd: int,
+                                wsp: Optional[dict] = None) -> torch.Tensor:
+        """``np.nanpercentile`` per (dayofyear window, cell), float32, layout ``[366, C]`` (detect.py:1921-1956)."""
+        self._bind_stream()
+        T_out, Cn = anom.shape
+        nd = np.diff(dcal.plan.doy_start).astype(np.int64)
+        half = int(wd) // 2
+        ext = np.concatenate([nd[-half:], nd, nd[:half]]) if half else nd
+        max_rows = int(np.convolve(ext, np.ones(wd, dtype=np.int64), mode="valid").max())
+        q32 = np.float32(percentile) / np.float32(100)  # NumPy's own float32 quantile (SURVEY A.8)
+        thr = self._buf(wsp, "thr_doy_major", (N_DOY, Cn), torch.float32, self.device)
+        overflow = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        rc = self.lib.marex_hobday_exact_f32(
+            self.ctx.handle, anom.data_ptr(), T_out, Cn, dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(),
+            max(max_rows, 1), float(q32), float(q32), int(wd), thr.data_ptr(), overflow.data_ptr(),
+        )
+        self.ctx.check(rc, "marex_hobday_exact_f32")
+        if int(overflow.item()) != 0:
+            raise ProcessingError("exact Hobday percentile: selection buffer overflow (internal sizing error)")
+        return thr
 
-    def hobday_thresholds_exact(self, anom, dcal, percentile, wd):
-        self._todo("exact Hobday percentile")
+    # ------------------------------------------------------------------ stage a14 global thresholds
+    def global_threshold(self, anom: torch.Tensor, percentile: float, method_percentile: str, bins: Optional[BinTable]):
+        """Per-cell constant threshold, float64 ``[C]`` (detect.py:2873-2912) + warning statistics."""
+        from .binning import global_bins
 
-    def global_threshold(self, anom, percentile, method_percentile, bins):
-        self._todo("global_extreme threshold")
+        self._bind_stream()
+        T_out, Cn = anom.shape
+        thr = torch.empty((Cn,), dtype=torch.float64, device=self.device)
+        q = float(percentile) / 100.0
+        if method_percentile == "exact":
+            rc = self.lib.marex_global_threshold_f32(
+                self.ctx.handle, anom.data_ptr(), T_out, Cn, q, 1, None, None, 0, 0.0, 0.0, thr.data_ptr(), None, None
+            )
+            self.ctx.check(rc, "marex_global_threshold_f32")
+            return {"thr_f64": thr, "stats": {"n_too_low": 0, "n_too_high": 0, "min": float("nan"), "max": float("nan")}}
+        gb = global_bins(bins.precision, bins.max_anomaly)
+        edges = self._dev(gb.edges.astype(np.float64))
+        centres = self._dev(gb.centres.astype(np.float64))
+        stats = torch.zeros((4,), dtype=torch.int32, device=self.device)
+        minmax = torch.tensor([float("inf"), float("-inf")], dtype=torch.float64, device=self.device)
+        rc = self.lib.marex_global_threshold_f32(
+            self.ctx.handle, anom.data_ptr(), T_out, Cn, q, 0, edges.data_ptr(), centres.data_ptr(), gb.nb,
+            float(gb.lower_bound), float(gb.upper_bound), thr.data_ptr(), stats.data_ptr(), minmax.data_ptr(),
+        )
+        self.ctx.check(rc, "marex_global_threshold_f32")
+        self.sync()
+        s = stats.cpu().numpy().view(np.uint32)
+        mm = minmax.cpu().numpy()
+        return {
+            "thr_f64": thr,
+            "stats": {
+                "n_too_low": int(s[2]), "n_too_high": int(s[3]),
+                "min": float(mm[0]) if np.isfinite(mm[0]) else float("nan"),
+                "max": float(mm[1]) if np.isfinite(mm[1]) else float("nan"),
+            },
+        }
 
-    def mask_ge_const(self, anom, thr):
-        self._todo("constant-threshold mask")
+    def mask_ge_const(self, anom: torch.Tensor, thr_f64: torch.Tensor, wsp: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+        self._bind_stream()
+        T_out, Cn = anom.shape
+        ext = self._buf(wsp, "extreme", (T_out, Cn), torch.uint8, self.device)
+        n_true = self._buf(wsp, "n_true", (1,), torch.int64, self.device)
+        n_true.zero_()
+        rc = self.lib.marex_mask_ge_const_f32(
+            self.ctx.handle, anom.data_ptr(), thr_f64.data_ptr(), T_out, Cn, ext.data_ptr(), n_true.data_ptr()
+        )
+        self.ctx.check(rc, "marex_mask_ge_const_f32")
+        return {"extreme": ext, "n_true": n_true}

@@ -379,9 +379,25 @@ def percentile_lerp_f32(v_sorted: np.ndarray, percentile: float) -> np.float32:
 # a14 global (constant-in-time) threshold                            detect.py:2737-2923
 # --------------------------------------------------------------------------------------
 def global_threshold_exact(anom: np.ndarray, percentile: float) -> np.ndarray:
-    """``DataArray.quantile(p/100, dim=time)`` == ``np.quantile`` (NaN-propagating) -> float64 ``[C]``."""
-    with np.errstate(invalid="ignore"):
-        return np.quantile(np.asarray(anom, dtype=np.float32), percentile / 100.0, axis=0).astype(np.float64)
+    """``DataArray.quantile(p/100, dim=time)`` -> float64 ``[C]`` (detect.py:2899).
+
+    xarray (absent here; restated from its documented behaviour) calls ``np.nanquantile`` with
+    ``q = np.atleast_1d(np.asarray(q, dtype=np.float64))`` for float data: NaNs are skipped, the
+    interpolation runs in float64 on the float32 order statistics, all-NaN cells give NaN.
+    Contract: NumPy's ``_quantile`` arithmetic applied PER CELL.  (``np.nanquantile`` itself runs
+    ``apply_along_axis``, whose output dtype is taken from the first slice -- float32 when that cell is
+    all-NaN -- so the reference's own result is float32- or float64-rounded depending on which cell
+    starts a Dask chunk; that accident is not reproduced.)
+    """
+    anom = np.asarray(anom, dtype=np.float32)
+    q = np.atleast_1d(np.asarray(percentile / 100.0, dtype=np.float64))
+    out = np.full(anom.shape[1], np.nan, dtype=np.float64)
+    for c in range(anom.shape[1]):
+        v = anom[:, c]
+        v = v[~np.isnan(v)]
+        if v.size:
+            out[c] = np.quantile(v, q)[0]
+    return out
 
 
 def global_threshold_approx(anom: np.ndarray, q: float, edges: np.ndarray, centres: np.ndarray):

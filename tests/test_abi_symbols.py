@@ -43,3 +43,44 @@ def test_host_modules_import_without_gpu():
     import marex_amd.engine  # noqa: F401
 
     assert callable(marex_amd.preprocess_data)
+
+
+def _header_signatures():
+    """name -> list of ctypes classes parsed from the C declarations in include/marex_hip.h."""
+    import ctypes as C
+
+    src = open(os.path.join(ROOT, "include", "marex_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    sigs = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(marex_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        name, params = m.group(1), m.group(2).strip()
+        kinds = []
+        if params and params != "void":
+            for prm in params.split(","):
+                prm = prm.strip()
+                if "*" in prm:
+                    kinds.append("ptr")
+                elif re.match(r"(u?int64_t)\b", prm):
+                    kinds.append("u64" if prm.startswith("uint64_t") else "i64")
+                elif prm.startswith("int "):
+                    kinds.append("i32")
+                elif prm.startswith("float "):
+                    kinds.append("f32")
+                elif prm.startswith("double "):
+                    kinds.append("f64")
+                else:
+                    raise AssertionError(f"unparsed parameter {prm!r} of {name}")
+        sigs[name] = kinds
+    return sigs
+
+
+def test_ctypes_prototypes_match_the_header_parameter_lists():
+    """A wrong argtypes list sends garbage pointers to a kernel (GPU fault): check arity AND kinds on the CPU."""
+    import ctypes as C
+
+    kind_of = {C.c_void_p: "ptr", C.c_int64: "i64", C.c_uint64: "u64", C.c_int: "i32", C.c_float: "f32", C.c_double: "f64"}
+    sigs = _header_signatures()
+    assert sorted(sigs) == sorted(_lib.PROTOTYPES)
+    for name, (_, argtypes) in _lib.PROTOTYPES.items():
+        got = ["ptr" if (a not in kind_of) else kind_of[a] for a in argtypes]  # POINTER(...) types count as pointers
+        assert got == sigs[name], f"{name}: binding {got} != header {sigs[name]}"

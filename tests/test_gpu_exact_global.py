@@ -1,0 +1,90 @@
+"""GPU parity: exact Hobday percentile, global thresholds (exact / approximate), constant-threshold mask."""
+import numpy as np
+import pytest
+import torch
+
+from marex_amd import binning, calendar, synth
+from oracle import marex_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _anomalies(hot, start, periods, ny, nx, W=4, S=21, mutate=None):
+    tm = calendar.daily_time_axis(start, periods)
+    x = synth.synth_field(synth.make_tables(tm, ny, nx))
+    if mutate is not None:
+        mutate(x)
+    cal_t = calendar.build_calendar(tm, window_year_baseline=W)
+    anom, _ = orc.shifting_baseline_anomaly(x, cal_t, W, S)
+    cal = calendar.build_calendar(tm[cal_t.kept])
+    return anom, cal
+
+
+@pytest.mark.parametrize("pct,wd", [(95.0, 11), (90.0, 5), (99.5, 31), (30.0, 11), (50.0, 3), (100.0, 11), (0.0, 11)])
+def test_exact_hobday_matches_numpy_nanpercentile(hot, pct, wd):
+    anom, cal = _anomalies(hot, "2000-01-01", 12 * 365 + 3, 6, 11)
+    exp = orc.hobday_thresholds_exact(anom, cal.doy_out, pct, wd)  # np.nanpercentile itself
+    dcal = hot.upload_calendar(cal)
+    a = torch.from_numpy(anom).to(hot.device)
+    thr = hot.hobday_thresholds_exact(a, dcal, pct, wd)
+    hot.sync()
+    got = thr.cpu().numpy()
+    assert got.shape == (366, anom.shape[1])
+    assert np.array_equal(got, exp, equal_nan=True)
+    m = hot.mask_ge_doy(a, thr, dcal)
+    exp_mask = orc.mask_ge_doy(anom, np.ascontiguousarray(exp.T), cal.doy_out)
+    assert np.array_equal(m["extreme"].cpu().numpy().astype(bool), exp_mask)
+
+
+def test_exact_hobday_with_nan_gaps_and_ties(hot):
+    def mutate(x):
+        ocean = np.flatnonzero(np.isfinite(x[0]))
+        x[2000:2300, ocean[1]] = np.nan
+        x[:, ocean[2]] = np.round(x[:, ocean[2]])  # many ties
+
+    anom, cal = _anomalies(hot, "1998-01-01", 10 * 365 + 3, 5, 9, mutate=mutate)
+    exp = orc.hobday_thresholds_exact(anom, cal.doy_out, 90.0, 11)
+    thr = hot.hobday_thresholds_exact(torch.from_numpy(anom).to(hot.device), hot.upload_calendar(cal), 90.0, 11)
+    hot.sync()
+    assert np.array_equal(thr.cpu().numpy(), exp, equal_nan=True)
+
+
+def test_percentile_lerp_mirror_is_numpy():
+    """The float32 interpolation the kernel follows == np.nanpercentile (runs on the CPU, kept with its GPU user)."""
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        m = int(rng.integers(1, 400))
+        v = rng.normal(0, 1, m).astype(np.float32)
+        p = float(rng.choice([60, 90, 95, 99, 12.5, 50]))
+        assert orc.percentile_lerp_f32(np.sort(v), p) == np.nanpercentile(v, p)
+
+
+@pytest.mark.parametrize("pct", [95.0, 60.0, 99.9])
+def test_global_exact_threshold_and_mask(hot, pct):
+    anom, cal = _anomalies(hot, "2002-01-01", 9 * 365 + 2, 5, 13)
+    exp = orc.global_threshold_exact(anom, pct)
+    a = torch.from_numpy(anom).to(hot.device)
+    g = hot.global_threshold(a, pct, "exact", None)
+    hot.sync()
+    got = g["thr_f64"].cpu().numpy()
+    assert got.dtype == np.float64 and np.array_equal(got, exp, equal_nan=True)
+    m = hot.mask_ge_const(a, g["thr_f64"])
+    assert np.array_equal(m["extreme"].cpu().numpy().astype(bool), orc.mask_ge_const(anom, exp))
+    assert int(m["n_true"].item()) == int(orc.mask_ge_const(anom, exp).sum())
+
+
+@pytest.mark.parametrize("pct", [95.0, 90.0])
+def test_global_approx_threshold(hot, pct):
+    anom, cal = _anomalies(hot, "2002-01-01", 9 * 365 + 2, 5, 13)
+    anom[:, 7] = 0.0  # constant anomaly -> clamped to edges[3] with a "too low" count
+    gb = binning.global_bins()
+    exp, st = orc.global_threshold_approx(anom, pct / 100.0, gb.edges, gb.centres)
+    g = hot.global_threshold(torch.from_numpy(anom).to(hot.device), pct, "approximate", binning.hobday_bins())
+    hot.sync()
+    got = g["thr_f64"].cpu().numpy()
+    assert np.array_equal(got, exp, equal_nan=True)
+    assert g["stats"]["n_too_low"] == st["n_too_low"] and g["stats"]["n_too_high"] == st["n_too_high"]
+    assert g["stats"]["min"] == st["min"] and g["stats"]["max"] == st["max"]
+    # within the reference's own tolerance of np.percentile for smooth data (tests/test_detect_helpers.py:172-233)
+    ocean = np.isfinite(anom[0]) & (np.arange(anom.shape[1]) != 7)
+    assert np.abs(got[ocean] - np.percentile(anom[:, ocean], pct, axis=0)).max() < 0.02
