@@ -1,0 +1,80 @@
+"""Statistical pins the reference's own tests put on this path, re-expressed on the oracle (CPU).
+
+The reference cannot run here (xarray / dask / flox absent), and it holds no numeric golden for these
+stages, only tolerances.  They are applied to the oracle so that the contract the GPU is
+held to bit-for-bit is itself inside the reference's acceptance bands.
+"""
+import numpy as np
+
+from marex_amd import binning, calendar, synth
+from oracle import marex_oracle as orc
+
+
+def _case(years=30, ny=8, nx=12, W=15):
+    tm = calendar.daily_time_axis("1990-01-01", years * 365 + 7)
+    x = synth.synth_field(synth.make_tables(tm, ny, nx))
+    cal = calendar.build_calendar(tm, window_year_baseline=W)
+    bt = binning.hobday_bins()
+    r = orc.preprocess_arrays(x, cal, ny=ny, nx=nx, window_year_baseline=W, edges=bt.edges, centres=bt.centres)
+    return tm, x, cal, bt, r
+
+
+def test_extreme_frequency_and_time_trim():
+    tm, x, cal, bt, r = _case()
+    # tests/test_gridded_preprocessing.py:71-88 -- first W years removed (+-10 d), 5 % +- 1 % extremes
+    assert abs((cal.T - cal.T_out) - 15 * 365) <= 10
+    freq = r["extreme_events"][:, r["mask"]].mean()
+    assert abs(freq - 0.05) <= 0.01
+    assert r["dat_anomaly"].dtype == np.float32 and r["thresholds"].dtype == np.float32
+    assert r["thresholds"].shape == (x.shape[1], 366)
+    assert np.isnan(r["thresholds"][~r["mask"]]).all() and (r["thresholds"][r["mask"]] > 0).all()
+    # the 0.02 degC/yr trend of the synthetic field shows up as the lag of a 15-yr trailing baseline
+    assert 0.05 < float(np.nanmean(r["dat_anomaly"])) < 0.30
+
+
+def test_histogram_quantile_vs_exact_hobday_within_three_bins():
+    # tests/test_detect_helpers.py:524-599: approximate within 3 bin widths of the exact percentile (no pooling)
+    tm, x, cal, bt, r = _case(years=24, ny=4, nx=6, W=4)
+    anom = r["dat_anomaly"]
+    approx, _ = orc.hobday_thresholds_approx(anom, cal.doy_out, 0.95, 11, None, bt.edges, bt.centres, 4, 6)
+    exact = orc.hobday_thresholds_exact(anom, cal.doy_out, 95.0, 11).T
+    ocean = r["mask"]
+    assert np.nanmax(np.abs(approx[ocean] - exact[ocean])) < 3 * 0.01 + 0.02  # sparse tails: 20 yr x 11 d samples
+
+
+def test_normal_data_quantile_levels():
+    # tests/test_detect_helpers.py:478-522, 639-690: N(0,1): q=.95 in [1, 2.2]; q=.9 mean ~ 1.2816 +- 0.015
+    rng = np.random.default_rng(42)
+    T = 40 * 365
+    tm = calendar.daily_time_axis("1980-01-01", T)
+    cal = calendar.build_calendar(tm)
+    bt = binning.hobday_bins()
+    anom = rng.normal(0, 1, (T, 5 * 5)).astype(np.float32)
+    t95, _ = orc.hobday_thresholds_approx(anom, cal.doy_out, 0.95, 21, 5, bt.edges, bt.centres, 5, 5)
+    assert t95.shape == (25, 366) and (t95 > 1.0).all() and (t95 < 2.2).all()
+    for wd in (11, 21, 41):
+        t90, _ = orc.hobday_thresholds_approx(anom, cal.doy_out, 0.90, wd, 5, bt.edges, bt.centres, 5, 5)
+        assert abs(float(t90.mean()) - 1.2816) < 0.015
+
+
+def test_constant_data_is_clamped_and_never_extreme():
+    # tests/test_detect_helpers.py:692-729 and SURVEY 8d "degenerate cfg1": constant anomaly 0 -> threshold edges[3]
+    tm = calendar.daily_time_axis("2001-01-01", 365)
+    cal = calendar.build_calendar(tm)
+    x = np.full((365, 6), 12.0, dtype=np.float32)
+    gb = binning.global_bins()
+    r = orc.preprocess_arrays(x, cal, ny=2, nx=3, method_anomaly="fixed_baseline", method_extreme="global_extreme",
+                              edges=gb.edges, centres=gb.centres)
+    assert (r["dat_anomaly"] == 0).all()
+    assert np.allclose(r["thresholds"], gb.edges[3]) and r["stats"]["n_too_low"] == 6
+    assert not r["extreme_events"].any()
+
+
+def test_one_dimensional_histogram_quantile_close_to_numpy():
+    # tests/test_detect_helpers.py:158-278: 1-D histogram quantile within 0.005-0.05 of np.percentile
+    rng = np.random.default_rng(7)
+    anom = rng.normal(0.2, 1.0, (20000, 4)).astype(np.float32)
+    gb = binning.global_bins()
+    for q in (0.9, 0.95, 0.99):
+        thr, _ = orc.global_threshold_approx(anom, q, gb.edges, gb.centres)
+        assert np.abs(thr - np.percentile(anom, 100 * q, axis=0)).max() < 0.02
