@@ -81,14 +81,17 @@ int marex_synth_sst_f32(marex_ctx* ctx, const float* mean, const float* amp, con
  *  rowb_index[T]            row of timestep t in the dayofyear-sorted bin matrix or -1
  *  first_valid_year         first calendar-year index that gets a climatology (= W)
  *  write_clim               0: out = x - clim (anomaly); 1: out = clim (rolling_climatology API)
- *  edges[nb+1], bins        bin table and output [T_out, C] uint16 (both may be NULL: no binning)
+ *  edges[nb+1], bins        bin table and output bin matrix, uint16, T_out rows (both may be NULL: no binning).
+ *                           BIN MATRIX LAYOUT (all entry points): blocks of 16 consecutive cells; element
+ *                           (row r, cell c) at ((c >> 4) * T_out + r) * 16 + (c & 15); ceil(C/16)*T_out*16 elements;
+ *                           rows are the kept timesteps sorted by (dayofyear, time) (rowb_index)
  *  mask[C]                  isfinite(x[0, c])                     (may be NULL)
  *  invalid_count[C]         number of non-finite x[t, c] over t; must be zeroed by the caller (may be NULL)
  */
 int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
                                 const int32_t* tindex, int n_cal_years, int first_valid_year,
                                 const int32_t* out_index, const int32_t* rowb_index, int W, int S,
-                                int write_clim, const float* edges, int nb, float* out,
+                                int write_clim, const float* edges, int nb, int64_t T_out, float* out,
                                 uint16_t* bins, uint8_t* mask, int32_t* invalid_count);
 
 /*
@@ -96,7 +99,7 @@ int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64
  * Replaces: the flox 2-D count + spatial pooling + per-cell _rolling_histogram_quantile +
  * NaN-masking + clamp of _compute_histogram_quantile_2d (detect.py:2638-2732, 2465-2559).
  *
- *  bins[T_out, C]     uint16 bin ids, rows sorted by (dayofyear, time) (see rowb_index above)
+ *  bins               uint16 bin matrix in the blocked layout described at marex_shifting_baseline_f32
  *  doy_start[367]     rows doy_start[d-1]..doy_start[d]-1 hold dayofyear d
  *  max_bucket         largest number of rows of one dayofyear (host knows doy_start); lets the kernel use
  *                     16-bit counters when max_bucket*wd*ws*ws <= 65535.  0 = unknown (32-bit counters)
@@ -140,7 +143,7 @@ int marex_fixed_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t 
 
 /* bins[rowb_index[t], c] = np.digitize(anom[t, c], edges) - 1 for rows with rowb_index[t] >= 0 (detect.py:2622-2631) */
 int marex_digitize_f32(marex_ctx* ctx, const float* anom, int64_t T, int64_t C, const int32_t* rowb_index,
-                       const float* edges, int nb, uint16_t* bins);
+                       const float* edges, int nb, int64_t T_out, uint16_t* bins);
 
 /*
  * Polynomial / harmonic detrend (detect.py:2143-2224).  pmodel[T, n_coef] = pinv(model) and

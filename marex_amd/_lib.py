@@ -36,7 +36,7 @@ PROTOTYPES = {
     "marex_synth_sst_f32": (_i32, [_p, _p, _p, _p, _p, _p, _p, _u64, _i64, _i64, _i64, _p]),
     "marex_shifting_baseline_f32": (
         _i32,
-        [_p, _p, _i64, _i64, _p, _i32, _i32, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p],
+        [_p, _p, _i64, _i64, _p, _i32, _i32, _p, _p, _i32, _i32, _i32, _p, _i32, _i64, _p, _p, _p, _p],
     ),
     "marex_hobday_thresholds_f32": (
         _i32,
@@ -45,7 +45,7 @@ PROTOTYPES = {
     "marex_mask_ge_doy_f32": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "marex_transpose_f32": (_i32, [_p, _p, _i64, _i64, _p]),
     "marex_fixed_baseline_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
-    "marex_digitize_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _p]),
+    "marex_digitize_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _i64, _p]),
     "marex_detrend_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
     "marex_hobday_exact_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _f32, _f64, _i32, _p, _p]),
     "marex_global_threshold_f32": (_i32, [_p, _p, _i64, _i64, _f64, _i32, _p, _p, _i32, _f64, _f64, _p, _p, _p]),

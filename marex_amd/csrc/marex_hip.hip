@@ -161,6 +161,14 @@ __device__ __forceinline__ bool xcd_swizzle(unsigned b, int n_outer, int n_inner
 }
 static inline unsigned xcd_grid(int n_outer, int n_inner) { return (unsigned)(((n_outer + 7) / 8) * 8) * (unsigned)n_inner; }
 
+// Bin matrix layout: blocks of 16 consecutive cells, inside a block the dayofyear-sorted rows are
+// contiguous: element (row r, cell c) at ((c >> 4) * T_out + r) * 16 + (c & 15).  The threshold kernel's
+// 16-cell-wide tile rows then read whole contiguous runs (a tile row's entire day window) instead of
+// 32 bytes out of every 128-byte line of a row-major [T_out, C] matrix (measured: 17x over-fetch).
+__device__ __forceinline__ size_t bins_index(long r, long c, long T_out) {
+    return ((size_t)(c >> 4) * (size_t)T_out + (size_t)r) * 16 + (size_t)(c & 15);
+}
+
 // np.digitize(v, edges) - 1 for an increasing table edges[0..nb] with edges[0] = -inf  (contract C4).
 // The guess assumes equal-width bins above edges[1]; the two correction loops make it exact for any
 // increasing table.
@@ -170,8 +178,13 @@ __device__ __forceinline__ int digitize_bin(float v, const float* e, int nb, flo
     if (v < e[1]) return 0;
     int k = 1 + (int)((v - e[1]) * inv_width);
     k = k < 1 ? 1 : (k > nb - 1 ? nb - 1 : k);
-    while (k > 1 && v < e[k]) --k;
-    while (k < nb - 1 && v >= e[k + 1]) ++k;
+    // the guess is off by at most one for equal-width tables: one branch-free correction, then verify
+    k += (v >= e[k + 1]) - (v < e[k]);
+    k = k < 1 ? 1 : (k > nb - 1 ? nb - 1 : k);
+    if (!(v >= e[k] && v < e[k + 1])) {  // arbitrary increasing tables: walk (never taken for uniform bins)
+        while (k > 1 && v < e[k]) --k;
+        while (k < nb - 1 && v >= e[k + 1]) ++k;
+    }
     return k;
 }
 
@@ -253,7 +266,7 @@ template <int D, int SCAP, bool SEXACT>
 __global__ void __launch_bounds__(256)
 k_shifting(const float* __restrict__ x, long T, long C, const int* __restrict__ tindex, int n_cal,
            int first_valid, const int* __restrict__ out_index, const int* __restrict__ rowb_index, int W,
-           int S_rt, int write_clim, const float* __restrict__ edges, int nb, float* __restrict__ out,
+           int S_rt, int write_clim, const float* __restrict__ edges, int nb, long T_out, float* __restrict__ out,
            unsigned short* __restrict__ bins, unsigned char* __restrict__ mask, int* __restrict__ invalid_count,
            int ncb, int nchunks) {
     extern __shared__ float lds[];
@@ -321,7 +334,7 @@ k_shifting(const float* __restrict__ x, long T, long C, const int* __restrict__ 
                         out[(size_t)oi * C + c] = write_clim ? clim : a;
                         if (do_bins) {
                             const int rb = rowb_index[t];
-                            bins[(size_t)rb * C + c] = (unsigned short)digitize_bin(a, e, nb, inv_width);
+                            bins[bins_index(rb, c, T_out)] = (unsigned short)digitize_bin(a, e, nb, inv_width);
                         }
                     }
                 }
@@ -330,6 +343,9 @@ k_shifting(const float* __restrict__ x, long T, long C, const int* __restrict__ 
         col[slot0 * 256] = (t >= 0) ? s : nan_f();
     };
 
+    // Inactive lanes (beyond C) stream the last cell instead of being masked off: loads stay unconditional
+    // and uniform in control flow; only the stores are guarded by `active`.
+    const unsigned cidx = active ? (unsigned)c : (unsigned)(C - 1);
     float xw[D + SCAP - 1];
     for (int y = 0; y < n_cal; ++y) {
         const int* trow = tindex + (size_t)y * NDOY + d0;
@@ -347,14 +363,23 @@ k_shifting(const float* __restrict__ x, long T, long C, const int* __restrict__ 
         if (fast) {
             const long r0 = (long)tt[0] - lo;
             const int nload = Dv + S - 1;
+            if (r0 >= 0 && r0 + nload <= T) {  // whole batch inside the series: no per-row checks
+                const float* rowp = x + (size_t)r0 * C;
 #pragma unroll
-            for (int j = 0; j < D + SCAP - 1; ++j) {
-                float v = nan_f();
-                if (j < nload) {
-                    const long row = r0 + j;
-                    if (active && row >= 0 && row < T) v = x[(size_t)row * C + c];
+                for (int j = 0; j < D + SCAP - 1; ++j) {
+                    if (j < nload) {
+                        xw[j] = rowp[cidx];
+                        rowp += C;
+                    }
                 }
-                xw[j] = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < D + SCAP - 1; ++j) {
+                    if (j < nload) {
+                        const long row = r0 + j;
+                        xw[j] = (row >= 0 && row < T) ? x[(size_t)row * C + cidx] : nan_f();
+                    }
+                }
             }
 #pragma unroll
             for (int i = 0; i < D; ++i) {
@@ -380,12 +405,10 @@ k_shifting(const float* __restrict__ x, long T, long C, const int* __restrict__ 
                         const long r0 = (long)tt[i] - lo;
 #pragma unroll
                         for (int k = 0; k < SCAP; ++k) {
-                            float v = nan_f();
                             if (k < S) {
                                 const long row = r0 + k;
-                                if (active && row >= 0 && row < T) v = x[(size_t)row * C + c];
+                                xw[k] = (row >= 0 && row < T) ? x[(size_t)row * C + cidx] : nan_f();
                             }
-                            xw[k] = v;
                         }
                         float acc = xw[0];
                         xc = (lo == 0) ? xw[0] : 0.f;
@@ -409,8 +432,8 @@ k_shifting(const float* __restrict__ x, long T, long C, const int* __restrict__ 
 template <int D, int SCAP, bool SEXACT>
 static int launch_shifting(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* tindex, int n_cal,
                            int first_valid, const int32_t* out_index, const int32_t* rowb_index, int W, int S,
-                           int write_clim, const float* edges, int nb, float* out, uint16_t* bins, uint8_t* mask,
-                           int32_t* invalid_count) {
+                           int write_clim, const float* edges, int nb, int64_t T_out, float* out, uint16_t* bins,
+                           uint8_t* mask, int32_t* invalid_count) {
     const int ncb = (int)((C + 255) / 256);
     const int nchunks = (NDOY + D - 1) / D;
     const size_t lds = ((size_t)D * W * 256 + (bins ? (size_t)nb + 1 : 0)) * sizeof(float);
@@ -420,8 +443,8 @@ static int launch_shifting(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
     {
         LaunchTimer lt(ctx, MAREX_K_SHIFTING);
         hipLaunchKernelGGL(kern, dim3(xcd_grid(ncb, nchunks)), dim3(256), lds, ctx->stream, x, (long)T, (long)C,
-                           tindex, n_cal, first_valid, out_index, rowb_index, W, S, write_clim, edges, nb, out,
-                           bins, mask, invalid_count, ncb, nchunks);
+                           tindex, n_cal, first_valid, out_index, rowb_index, W, S, write_clim, edges, nb, (long)T_out,
+                           out, bins, mask, invalid_count, ncb, nchunks);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -430,9 +453,9 @@ static int launch_shifting(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
 template <int SCAP, bool SEXACT>
 static int dispatch_shifting_D(int D, marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* tindex,
                                int n_cal, int first_valid, const int32_t* out_index, const int32_t* rowb_index,
-                               int W, int S, int write_clim, const float* edges, int nb, float* out,
-                               uint16_t* bins, uint8_t* mask, int32_t* invalid_count) {
-#define MAREX_ARGS ctx, x, T, C, tindex, n_cal, first_valid, out_index, rowb_index, W, S, write_clim, edges, nb, out, bins, mask, invalid_count
+                               int W, int S, int write_clim, const float* edges, int nb, int64_t T_out,
+                               float* out, uint16_t* bins, uint8_t* mask, int32_t* invalid_count) {
+#define MAREX_ARGS ctx, x, T, C, tindex, n_cal, first_valid, out_index, rowb_index, W, S, write_clim, edges, nb, T_out, out, bins, mask, invalid_count
     switch (D) {
         case 8: return launch_shifting<8, SCAP, SEXACT>(MAREX_ARGS);
         case 4: return launch_shifting<4, SCAP, SEXACT>(MAREX_ARGS);
@@ -450,26 +473,28 @@ static int env_int(const char* name, int dflt) {
 extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
                                            const int32_t* tindex, int n_cal_years, int first_valid_year,
                                            const int32_t* out_index, const int32_t* rowb_index, int W, int S,
-                                           int write_clim, const float* edges, int nb, float* out, uint16_t* bins,
-                                           uint8_t* mask, int32_t* invalid_count) {
+                                           int write_clim, const float* edges, int nb, int64_t T_out, float* out,
+                                           uint16_t* bins, uint8_t* mask, int32_t* invalid_count) {
     if (!ctx) return -1;
     if (!x || !tindex || !out_index || !out || T <= 0 || C <= 0 || n_cal_years <= 0)
         return fail(ctx, -1, "marex_shifting_baseline_f32: null pointer or empty shape");
     if (W < 1 || S < 1) return fail(ctx, -1, "marex_shifting_baseline_f32: W and S must be >= 1");
     if (S > 128) return fail(ctx, -4, "marex_shifting_baseline_f32: smooth_days_baseline > 128 is not supported");
-    if (bins && (!edges || !rowb_index || nb < 4 || nb > 65534))
-        return fail(ctx, -1, "marex_shifting_baseline_f32: binning needs edges, rowb_index and 4 <= nb <= 65534");
+    if (bins && (!edges || !rowb_index || nb < 4 || nb > 65534 || T_out <= 0))
+        return fail(ctx, -1, "marex_shifting_baseline_f32: binning needs edges, rowb_index, T_out and 4 <= nb <= 65534");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // largest dayofyear chunk whose LDS ring leaves room for two workgroups per CU
     const size_t budget = 72 * 1024, extra = bins ? ((size_t)nb + 1) * 4 : 0;
     int D = env_int("MAREX_SHIFT_D", 0);
     if (D != 1 && D != 2 && D != 4 && D != 8) {
-        D = 4;
+        // 8 dayofyears per workgroup (3.5 row loads per output) while three workgroups still fit a CU,
+        // otherwise the largest chunk that leaves room for two
+        D = ((size_t)8 * W * 1024 + extra <= 48 * 1024) ? 8 : 4;
         while (D > 1 && (size_t)D * W * 1024 + extra > budget) D >>= 1;
     }
     if ((size_t)D * W * 1024 + extra > 80 * 1024)
         return fail(ctx, -4, "marex_shifting_baseline_f32: window_year_baseline=%d needs more than 80 KiB of LDS", W);
-#define MAREX_ARGS D, ctx, x, T, C, tindex, n_cal_years, first_valid_year, out_index, rowb_index, W, S, write_clim, edges, nb, out, bins, mask, invalid_count
+#define MAREX_ARGS D, ctx, x, T, C, tindex, n_cal_years, first_valid_year, out_index, rowb_index, W, S, write_clim, edges, nb, T_out, out, bins, mask, invalid_count
     if (S == 21) return dispatch_shifting_D<21, true>(MAREX_ARGS);
     if (S <= 8) return dispatch_shifting_D<8, false>(MAREX_ARGS);
     if (S <= 32) return dispatch_shifting_D<32, false>(MAREX_ARGS);
@@ -513,7 +538,7 @@ __device__ __forceinline__ void hadd(unsigned* h, int b, int delta) {
 
 template <bool PACK>
 __global__ void __launch_bounds__(256)
-k_thresholds(const unsigned short* __restrict__ bins, long C, int ny, int nx, int nseg_per_row, long nsegs,
+k_thresholds(const unsigned short* __restrict__ bins, long T_out, long C, int ny, int nx, int nseg_per_row, long nsegs,
              int NW, const int* __restrict__ doy_start, const float* __restrict__ first_anom,
              const float* __restrict__ centres, int nb, double q, int wd, int p, float lower_bound,
              float upper_bound, int row0, float* __restrict__ thr, marex_thr_stats* __restrict__ stats) {
@@ -586,13 +611,13 @@ k_thresholds(const unsigned short* __restrict__ bins, long C, int ny, int nx, in
     };
     // stream one bucket (rows r0 .. r0+nd-1 of the lane's column), 4 independent loads in flight
     auto stream_bucket = [&](const CellMap& m, int r0, int nd, int sgn, int& nvalid, int& n0, int& n1) {
-        const unsigned short* col = bins + (size_t)r0 * C + m.coloff;
+        const unsigned short* col = bins + bins_index(r0, m.coloff, T_out);
         for (int r = slot; r < nd; r += 4 * nslot) {
             int bb[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int ru = r + u * nslot;
-                bb[u] = ru < nd ? (int)col[(size_t)ru * C] : nb;
+                bb[u] = ru < nd ? (int)col[(size_t)ru * 16] : nb;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) one_sample(m, bb[u], sgn, nvalid, n0, n1);
@@ -722,7 +747,7 @@ k_thresholds(const unsigned short* __restrict__ bins, long C, int ny, int nx, in
 
 template <int P, int TC>
 __global__ void __launch_bounds__(256)
-k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int row0, int row1, int tiles_x,
+k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, int nx, int row0, int row1, int tiles_x,
            int Dd, int shift, int env_exact, const int* __restrict__ doy_start,
            const float* __restrict__ first_anom, const float* __restrict__ centres, int nb, double q, int wd,
            float lower_bound, float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats) {
@@ -779,7 +804,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int 
         const int k = b - B0;
         return k < 0 ? 0 : (k >= BW ? BW + 1 : k + 1);
     };
-    const unsigned short* colbase = bins + cell;
+    const unsigned short* colbase = bins + bins_index(0, cell_valid ? cell : 0, T_out);  // rows are 16 elements apart
     // first TB_PRE samples of a dayofyear bucket of this lane's cell, kept in registers
     struct Pre {
         int b[TB_PRE];
@@ -789,9 +814,9 @@ k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int 
         Pre pr;
         pr.r0 = doy_start[d0];
         pr.nd = cell_valid ? doy_start[d0 + 1] - pr.r0 : 0;  // lanes outside the grid never touch memory
-        const unsigned short* col = colbase + (size_t)pr.r0 * C;
+        const unsigned short* col = colbase + (size_t)pr.r0 * 16;
 #pragma unroll
-        for (int u = 0; u < TB_PRE; ++u) pr.b[u] = (u < pr.nd) ? (int)col[(size_t)u * C] : nb;
+        for (int u = 0; u < TB_PRE; ++u) pr.b[u] = (u < pr.nd) ? (int)col[(size_t)u * 16] : nb;
         return pr;
     };
     auto bump = [&](int b, int sgn) {
@@ -804,11 +829,11 @@ k_thr_band(const unsigned short* __restrict__ bins, long C, int ny, int nx, int 
 #pragma unroll
         for (int u = 0; u < TB_PRE; ++u) bump(pr.b[u], sgn);
         if (pr.nd > TB_PRE) {  // long buckets (many years): stream the rest, 4 loads in flight
-            const unsigned short* col = colbase + (size_t)pr.r0 * C;
+            const unsigned short* col = colbase + (size_t)pr.r0 * 16;
             for (int r = TB_PRE; r < pr.nd; r += 4) {
                 int bb[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) bb[u] = (r + u < pr.nd) ? (int)col[(size_t)(r + u) * C] : nb;
+                for (int u = 0; u < 4; ++u) bb[u] = (r + u < pr.nd) ? (int)col[(size_t)(r + u) * 16] : nb;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) bump(bb[u], sgn);
             }
@@ -1119,7 +1144,7 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
         if (Dd < 1 || Dd > TB_DMAX) Dd = TB_DMAX;
         const int tiles_x = (nx + OC - 1) / OC, tiles_y = (row1 - row0 + OR - 1) / OR;
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((NDOY + Dd - 1) / Dd));
-#define MAREX_BAND_ARGS bins, (long)C, ny, nx, row0, row1, tiles_x, Dd, shift, env_int("MAREX_THR_EXACT_PATH", 0), doy_start, first_anom, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats
+#define MAREX_BAND_ARGS bins, (long)T_out, (long)C, ny, nx, row0, row1, tiles_x, Dd, shift, env_int("MAREX_THR_EXACT_PATH", 0), doy_start, first_anom, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats
         {
             LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
             if (TR == 1)
@@ -1155,8 +1180,8 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
-        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, ctx->stream, bins, (long)C, ny, nx, nseg_per_row,
-                           nsegs, NW, doy_start, first_anom, centres, nb, q, wd, ws / 2, lower_bound, upper_bound,
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, ctx->stream, bins, (long)T_out, (long)C, ny, nx,
+                           nseg_per_row, nsegs, NW, doy_start, first_anom, centres, nb, q, wd, ws / 2, lower_bound, upper_bound,
                            row0, thr_doy_major, stats);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1296,7 +1321,7 @@ k_fixed_baseline(const float* __restrict__ x, long T, long C, const int* __restr
         const int t = doy_rows[r];
         const float a = x[(size_t)t * C + c] - clim;
         out[(size_t)t * C + c] = a;
-        if (do_bins) bins[(size_t)r * C + c] = (unsigned short)digitize_bin(a, e, nb, inv_width);
+        if (do_bins) bins[bins_index(r, c, T)] = (unsigned short)digitize_bin(a, e, nb, inv_width);
     }
     if (invalid_count && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
 }
@@ -1328,7 +1353,7 @@ extern "C" int marex_fixed_baseline_f32(marex_ctx* ctx, const float* x, int64_t 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_digitize(const float* __restrict__ anom, long T, long C, const int* __restrict__ rowb_index,
-           const float* __restrict__ edges, int nb, int rows_per_block, unsigned short* __restrict__ bins) {
+           const float* __restrict__ edges, int nb, int rows_per_block, long T_out, unsigned short* __restrict__ bins) {
     extern __shared__ float e[];
     for (int i = threadIdx.x; i <= nb; i += 256) e[i] = edges[i];
     __syncthreads();
@@ -1339,14 +1364,14 @@ k_digitize(const float* __restrict__ anom, long T, long C, const int* __restrict
     const long t1 = t0 + rows_per_block < T ? t0 + rows_per_block : T;
     for (long t = t0; t < t1; ++t) {
         const int rb = rowb_index[t];
-        if (rb >= 0) bins[(size_t)rb * C + c] = (unsigned short)digitize_bin(anom[(size_t)t * C + c], e, nb, inv_width);
+        if (rb >= 0) bins[bins_index(rb, c, T_out)] = (unsigned short)digitize_bin(anom[(size_t)t * C + c], e, nb, inv_width);
     }
 }
 
 extern "C" int marex_digitize_f32(marex_ctx* ctx, const float* anom, int64_t T, int64_t C, const int32_t* rowb_index,
-                                  const float* edges, int nb, uint16_t* bins) {
+                                  const float* edges, int nb, int64_t T_out, uint16_t* bins) {
     if (!ctx) return -1;
-    if (!anom || !rowb_index || !edges || !bins || T <= 0 || C <= 0 || nb < 4 || nb > 36000)
+    if (!anom || !rowb_index || !edges || !bins || T <= 0 || C <= 0 || nb < 4 || nb > 36000 || T_out <= 0)
         return fail(ctx, -1, "marex_digitize_f32: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int rows = 32;
@@ -1357,7 +1382,7 @@ extern "C" int marex_digitize_f32(marex_ctx* ctx, const float* anom, int64_t T, 
     {
         LaunchTimer lt(ctx, MAREX_K_FIXED);
         hipLaunchKernelGGL(k_digitize, grid, dim3(256), lds, ctx->stream, anom, (long)T, (long)C, rowb_index, edges, nb,
-                           rows, bins);
+                           rows, (long)T_out, bins);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;

@@ -84,6 +84,17 @@ class HotPath:
     def sync(self) -> None:
         self.ctx.sync()
 
+    @staticmethod
+    def bins_shape(T_out: int, C: int):
+        """Shape of the blocked bin matrix: ``[ceil(C/16), T_out, 16]`` (include/marex_hip.h)."""
+        return ((C + 15) // 16, T_out, 16)
+
+    @staticmethod
+    def bins_to_rows(binsb: torch.Tensor, C: int) -> torch.Tensor:
+        """Blocked bin matrix -> plain ``[T_out, C]`` (dayofyear-sorted rows); for tests / inspection."""
+        nblk, T_out, _ = binsb.shape
+        return binsb.permute(1, 0, 2).reshape(T_out, nblk * 16)[:, :C]
+
     def bin_tables(self, bins: BinTable):
         """(edges, centres) of a bin table on the device, uploaded once per table object."""
         key = id(bins)
@@ -140,7 +151,7 @@ class HotPath:
         invalid.zero_()
         if bins is not None and not write_clim:
             edges = self.bin_tables(bins)[0]
-            binsb = self._buf(wsp, "bins", (T_out, Cn), torch.int16, self.device)
+            binsb = self._buf(wsp, "bins", self.bins_shape(T_out, Cn), torch.int16, self.device)
             e_ptr, b_ptr, nb = edges.data_ptr(), binsb.data_ptr(), bins.nb
         else:
             edges = binsb = None
@@ -148,7 +159,7 @@ class HotPath:
         rc = self.lib.marex_shifting_baseline_f32(
             self.ctx.handle, x.data_ptr(), T, Cn, dcal.tindex.data_ptr(), cal.n_cal_years, int(W),
             dcal.out_index.data_ptr(), dcal.rowb_index.data_ptr(), int(W), int(S), int(write_clim),
-            e_ptr, nb, out.data_ptr(), b_ptr, mask.data_ptr(), invalid.data_ptr(),
+            e_ptr, nb, T_out, out.data_ptr(), b_ptr, mask.data_ptr(), invalid.data_ptr(),
         )
         self.ctx.check(rc, "marex_shifting_baseline_f32")
         res = {"out": out, "mask": mask, "invalid_count": invalid, "_keep": edges}
@@ -173,7 +184,7 @@ class HotPath:
     ) -> Dict[str, object]:
         """``rows=(row0, row1)`` restricts the output to the grid rows a latitude shard owns."""
         self._bind_stream()
-        T_out, Cn = binsb.shape
+        T_out, Cn = binsb.shape[1], first_anom.shape[-1]
         row0, row1 = rows if rows is not None else (0, max(ny, 1))
         thr = self._buf(wsp, "thr_doy_major", (N_DOY, Cn), torch.float32, self.device)
         stats = self._buf(wsp, "thr_stats", (4,), torch.int32, self.device)
@@ -290,7 +301,7 @@ class HotPath:
         invalid.zero_()
         if bins is not None:
             edges = self.bin_tables(bins)[0]
-            binsb = self._buf(wsp, "bins", (T, Cn), torch.int16, self.device)
+            binsb = self._buf(wsp, "bins", self.bins_shape(T, Cn), torch.int16, self.device)
             e_ptr, b_ptr, nb = edges.data_ptr(), binsb.data_ptr(), bins.nb
         else:
             binsb, e_ptr, b_ptr, nb = None, None, None, 0
@@ -313,9 +324,10 @@ class HotPath:
         self._bind_stream()
         T, Cn = anom.shape
         edges = self.bin_tables(bins)[0]
-        binsb = self._buf(wsp, "bins", (dcal.plan.T_out, Cn), torch.int16, self.device)
+        binsb = self._buf(wsp, "bins", self.bins_shape(dcal.plan.T_out, Cn), torch.int16, self.device)
         rc = self.lib.marex_digitize_f32(
-            self.ctx.handle, anom.data_ptr(), T, Cn, dcal.rowb_index.data_ptr(), edges.data_ptr(), bins.nb, binsb.data_ptr()
+            self.ctx.handle, anom.data_ptr(), T, Cn, dcal.rowb_index.data_ptr(), edges.data_ptr(), bins.nb,
+            dcal.plan.T_out, binsb.data_ptr(),
         )
         self.ctx.check(rc, "marex_digitize_f32")
         return binsb

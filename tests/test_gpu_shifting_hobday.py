@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from marex_amd import binning, calendar, synth
+from marex_amd.engine import HotPath
 from oracle import marex_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -54,15 +55,13 @@ def check_all(x, cal, bt, exp, got):
     assert int(np.where(exp["mask"], inv, 0).max()) == v["max_invalid"]
     # bins: device rows are dayofyear-sorted
     bins_exp = orc.digitize_bins(exp["dat_anomaly"], bt.edges)[cal.doy_rows]
-    bins_got = got["_keep"][2].cpu().numpy().view(np.uint16)
+    bins_got = HotPath.bins_to_rows(got["_keep"][2], x.shape[1]).cpu().numpy().view(np.uint16)
     assert np.array_equal(bins_got, bins_exp)
     thr = got["thresholds"].cpu().numpy()
     assert _same_f32(thr, exp["thresholds"]), "thresholds differ from the oracle"
     ext = got["extreme_events"].cpu().numpy().astype(bool)
     assert np.array_equal(ext, exp["extreme_events"]), "extreme_events mask differs"
     assert int(got["n_true"].item()) == int(exp["extreme_events"].sum())
-    from marex_amd.engine import HotPath
-
     st = HotPath.decode_thr_stats(got["stats_dev"])
     assert st["n_too_low"] == exp["stats"]["n_too_low"] and st["n_too_high"] == exp["stats"]["n_too_high"]
     if np.isfinite(exp["stats"]["max"]):
