@@ -99,10 +99,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # MAREX_BENCH_BACKEND=gloo + MAREX_BENCH_ONE_GPU=1: rehearse the multi-rank path on a single-GPU box
+    backend = os.environ.get("MAREX_BENCH_BACKEND", "nccl")
+    if os.environ.get("MAREX_BENCH_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     wl = WORKLOADS[args.workload]
     T, nx, W = wl["T"], wl["nx"], wl["W"]
@@ -135,6 +142,8 @@ def main():
         ])
         mx = inv.max().to(torch.int64).reshape(1)
         if world > 1:
+            if backend != "nccl":  # gloo reduces host tensors
+                local, mx = local.cpu(), mx.cpu()
             dist.all_reduce(local, op=dist.ReduceOp.SUM)
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         return r, local, mx
@@ -156,7 +165,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     hot.sync()
-    tmax = torch.tensor([dt], dtype=torch.float64, device=hot.device)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=hot.device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

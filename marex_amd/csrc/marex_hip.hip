@@ -742,19 +742,22 @@ k_thresholds(const unsigned short* __restrict__ bins, long T_out, long C, int ny
 // of the 25-fold spatial fan-out that dominates the sliding-histogram kernel above.
 // ------------------------------------------------------------------------------------------------
 #define TB_NLP 33
+#define TB_LS 34
 #define TB_DMAX 32
 #define TB_PRE 8
 
-template <int P, int TC>
-__global__ void __launch_bounds__(256)
+template <int P, int TC, int NT>
+__global__ void __launch_bounds__(NT)
 k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, int nx, int row0, int row1, int tiles_x,
-           int Dd, int shift, int env_exact, const int* __restrict__ doy_start,
+           int Dd, int shift, int env_exact, int ablate, const int* __restrict__ doy_start,
            const float* __restrict__ first_anom, const float* __restrict__ centres, int nb, double q, int wd,
            float lower_bound, float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats) {
-    constexpr int TR = 256 / TC;
+    constexpr int TR = NT / TC;
     constexpr int OR = TR - 2 * P, OC = TC - 2 * P;
-    __shared__ unsigned lev[TB_NLP][256];
-    __shared__ unsigned char gst[TB_DMAX][256];
+    // lane-major level columns: TB_LS dwords (= 68 uint16 levels) per lane.  The stride 34 keeps 8-byte
+    // alignment and makes 8-byte accesses of 32 consecutive lanes hit 64 distinct banks.
+    __shared__ unsigned lev[NT * TB_LS];
+    __shared__ unsigned char gst[NT > 256 ? 16 : TB_DMAX][NT];  // the host limits Dd to 16 for 1024-thread tiles
     __shared__ int s_gmin, s_gmax, s_unres;
 
     const int t = threadIdx.x;
@@ -789,7 +792,9 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         return;
     }
 
-    for (int r = 0; r < TB_NLP; ++r) lev[r][t] = 0u;
+    unsigned* mycol = &lev[t * TB_LS];
+    uint2* mycol2 = reinterpret_cast<uint2*>(mycol);
+    for (int r = 0; r < TB_LS / 2; ++r) mycol2[r] = make_uint2(0u, 0u);
     if (t == 0) {
         s_gmin = 255;
         s_gmax = -1;
@@ -822,7 +827,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
     auto bump = [&](int b, int sgn) {
         if (b < nb) {
             const int k = lvl(b);
-            atomicAdd(&lev[k >> 1][t], (unsigned)sgn * (1u << ((k & 1) * 16)));
+            atomicAdd(&mycol[k >> 1], (unsigned)sgn * (1u << ((k & 1) * 16)));
         }
     };
     auto apply_bucket = [&](const Pre& pr, int sgn) {
@@ -839,82 +844,110 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
             }
         }
     };
+    // in-place inclusive prefix sum / its inverse over the lane's column, four levels per 8-byte access
     auto prefix = [&](int nlp) {
         unsigned run = 0;
+        const int n2 = (nlp + 1) >> 1;
 #pragma unroll 4
-        for (int r = 0; r < nlp; ++r) {
-            const unsigned w = lev[r][t];
-            const unsigned a = (w & 0xFFFFu) + run, b = (w >> 16) + a;
-            run = b;
-            lev[r][t] = a | (b << 16);
+        for (int i = 0; i < n2; ++i) {
+            const uint2 w = mycol2[i];
+            const unsigned a0 = (w.x & 0xFFFFu) + run, a1 = (w.x >> 16) + a0;
+            const unsigned a2 = (w.y & 0xFFFFu) + a1, a3 = (w.y >> 16) + a2;
+            run = a3;
+            mycol2[i] = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
         }
     };
     auto unprefix = [&](int nlp) {
         unsigned prev = 0;
+        const int n2 = (nlp + 1) >> 1;
 #pragma unroll 4
-        for (int r = 0; r < nlp; ++r) {
-            const unsigned w = lev[r][t];
-            const unsigned a = w & 0xFFFFu, b = w >> 16;
-            lev[r][t] = (a - prev) | ((b - a) << 16);
-            prev = b;
+        for (int i = 0; i < n2; ++i) {
+            const uint2 w = mycol2[i];
+            const unsigned a0 = w.x & 0xFFFFu, a1 = w.x >> 16, a2 = w.y & 0xFFFFu, a3 = w.y >> 16;
+            mycol2[i] = make_uint2((a0 - prev) | ((a1 - a0) << 16), (a2 - a1) | ((a3 - a2) << 16));
+            prev = a3;
         }
     };
-    // pooled cumulative count at level k of this lane's (2P+1)^2 neighbourhood (unrolled 16-bit LDS reads)
-    const unsigned short* lev16 = reinterpret_cast<const unsigned short*>(&lev[0][0]);
+    // pooled cumulative count at ONE level k of this lane's (2P+1)^2 neighbourhood
     auto pooled = [&](int k) {
-        const unsigned short* row = lev16 + ((size_t)(k >> 1) * 256 + t) * 2 + (k & 1);
+        const unsigned* base = mycol + (k >> 1);
+        const int sh16 = (k & 1) * 16;
         int sum = 0;
 #pragma unroll
         for (int dr = -P; dr <= P; ++dr)
 #pragma unroll
-            for (int dc = -P; dc <= P; ++dc) sum += (int)row[(dr * TC + dc) * 2];
+            for (int dc = -P; dc <= P; ++dc) sum += (int)((base[(dr * TC + dc) * TB_LS] >> sh16) & 0xFFFFu);
         return sum;
     };
-    // smallest k in [klo, khi) with pooled(k) > qpos (khi if none).  With `counts`: ck = pooled(k) and
-    // cb = pooled(k-1) (0 for k == 0) on return.
-    auto find_level = [&](int hint, int klo, int khi, double qpos, bool counts, int& ck, int& cb) {
-        int k;
-        bool have_cb = false;
+    // pooled cumulative counts at the EIGHT levels start .. start+7 (start % 4 == 0, start <= 60): two 8-byte
+    // reads per neighbour, packed 16-bit adds (the host guarantees pooled counts < 65536)
+    auto window = [&](int start, int (&Wv)[8]) {
+        const unsigned* base = mycol + (start >> 1);
+        unsigned a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+        for (int dr = -P; dr <= P; ++dr)
+#pragma unroll
+            for (int dc = -P; dc <= P; ++dc) {
+                const uint2* p2 = reinterpret_cast<const uint2*>(base + (dr * TC + dc) * TB_LS);
+                const uint2 u = p2[0], v = p2[1];
+                a0 += u.x;
+                a1 += u.y;
+                a2 += v.x;
+                a3 += v.y;
+            }
+        Wv[0] = (int)(a0 & 0xFFFFu);
+        Wv[1] = (int)(a0 >> 16);
+        Wv[2] = (int)(a1 & 0xFFFFu);
+        Wv[3] = (int)(a1 >> 16);
+        Wv[4] = (int)(a2 & 0xFFFFu);
+        Wv[5] = (int)(a2 >> 16);
+        Wv[6] = (int)(a3 & 0xFFFFu);
+        Wv[7] = (int)(a3 >> 16);
+    };
+    // Smallest level k < khi whose pooled cumulative count exceeds qpos (khi if none); ck = that count,
+    // cb = the count at k-1 (0 for k == 0).  Counts are integers, so "count <= qpos" is the integer test
+    // "count <= floor(qpos)".  The 8-level window starts two levels below the hint (previous day's level)
+    // and slides by four until it brackets the answer -- one pass in the common case.
+    auto find_level = [&](int hint, int klo, int khi, double qpos, bool /*counts*/, int& ck, int& cb) {
+        const int qf = (int)floor(qpos);
+        int top = (khi - 1) & ~3;  // last useful window start
+        if (top > 60) top = 60;
+        if (top < 0) top = 0;
+        int start = ((hint >= 0 ? hint : ((klo + khi) >> 1)) - 2) & ~3;
+        start = start < 0 ? 0 : (start > top ? top : start);
         ck = 0;
         cb = 0;
-        if (hint < klo || hint >= khi) {  // no usable hint: bisection over [klo, khi]
-            int lo = klo, hi = khi;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if ((double)pooled(mid) > qpos)
-                    hi = mid;
-                else
-                    lo = mid + 1;
-            }
-            k = lo;
-            if (counts && k < khi) ck = pooled(k);
-        } else {
-            k = hint;
-            ck = pooled(k);
-            if ((double)ck > qpos) {
-                while (k > klo) {
-                    const int cm = pooled(k - 1);
-                    if ((double)cm > qpos) {
-                        --k;
-                        ck = cm;
-                    } else {
-                        cb = cm;
-                        have_cb = true;
-                        break;
-                    }
+        for (;;) {
+            int Wv[8];
+            window(start, Wv);
+            const int m = (khi - start) < 8 ? (khi - start) : 8;  // levels >= khi do not exist
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) n += (i < m) && (Wv[i] <= qf);
+            if (n == 0) {
+                if (start == 0) {
+                    ck = Wv[0];
+                    return 0;
                 }
-            } else {
-                do {
-                    cb = ck;
-                    have_cb = true;
-                    ++k;
-                    if (k >= khi) break;
-                    ck = pooled(k);
-                } while (!((double)ck > qpos));
+                start -= 4;  // the answer is at or below `start`: bring level start-1 into view
+                continue;
             }
+            if (n == m) {
+                if (m < 8 || start >= top) {  // no existing level exceeds qpos
+                    cb = Wv[m - 1];
+                    return khi;
+                }
+                start += 4;
+                continue;
+            }
+            cb = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i == n - 1) cb = Wv[i];
+                if (i == n) ck = Wv[i];
+            }
+            return start + n;
         }
-        if (counts && !have_cb && k > 0) cb = pooled(k - 1);
-        return k;
     };
 
     unsigned kmin = 0xFFFFFFFFu, kmax = 0u, nlow = 0u, nhigh = 0u;
@@ -969,27 +1002,31 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
             const int d = d_begin + dd;
             // ---------------- P1: this lane's column
             if (dd == 0) {
-                for (int r = 0; r < nlp; ++r) lev[r][t] = 0u;
-                Pre cur = load_bucket(((d - pd) % NDOY + NDOY) % NDOY);
-                for (int o = -pd + 1; o <= pd; ++o) {
-                    const Pre nxt = load_bucket(((d + o) % NDOY + NDOY) % NDOY);
+                for (int r = 0; r < TB_LS / 2; ++r) mycol2[r] = make_uint2(0u, 0u);
+                if (!(ablate & 4)) {
+                    Pre cur = load_bucket(((d - pd) % NDOY + NDOY) % NDOY);
+                    for (int o = -pd + 1; o <= pd; ++o) {
+                        const Pre nxt = load_bucket(((d + o) % NDOY + NDOY) % NDOY);
+                        apply_bucket(cur, +1);
+                        cur = nxt;
+                    }
                     apply_bucket(cur, +1);
-                    cur = nxt;
                 }
-                apply_bucket(cur, +1);
             } else {
-                unprefix(nlp);
-                apply_bucket(pin, +1);
-                apply_bucket(pout, -1);
+                if (!(ablate & 2)) unprefix(nlp);
+                if (!(ablate & 4)) {
+                    apply_bucket(pin, +1);
+                    apply_bucket(pout, -1);
+                }
             }
-            prefix(nlp);
-            if (dd + 1 < nd_pass) {
+            if (!(ablate & 2)) prefix(nlp);
+            if (dd + 1 < nd_pass && !(ablate & 4)) {
                 pin = load_bucket((d + 1 + pd) % NDOY);
                 pout = load_bucket(((d - pd) % NDOY + NDOY) % NDOY);
             }
             __syncthreads();
             // ---------------- P2: quantile level of this lane's output cell
-            const int g = gst[dd][t];
+            const int g = (ablate & 1) ? 255 : gst[dd][t];
             if (mode == 0) {
                 if (g == 254) {
                     const int tot = pooled(nlev - 1);
@@ -1015,7 +1052,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
                         int ck, cb;
                         const int k = find_level(hint, 1, BW + 1, qpos, true, ck, cb);
                         // inside the band iff cs[B0-1] <= qpos (k == 1 needs the check) and some band bin exceeds qpos
-                        const bool ok = (k <= BW) && (k > 1 || !((double)cb > qpos));
+                        const bool ok = k >= 1 && k <= BW;
                         if (ok) {
                             hint = k;
                             emit_threshold(d, B0 + k - 1, ck, cb, qpos);
@@ -1073,7 +1110,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         s_unres = 1;
     }
     __syncthreads();
-    if (s_unres) {  // exact path for whatever is not resolved yet
+    if (s_unres && !(ablate & 8)) {  // exact path for whatever is not resolved yet
         for (int dd = 0; dd < ndays; ++dd)
             if (gst[dd][t] < 254) gst[dd][t] = 254;  // day-0 groups of a skipped speculative sweep: redo
         __syncthreads();
@@ -1136,25 +1173,34 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
     while ((((nb - 1) >> shift) + 1) > 32) ++shift;  // at most 32 coarse groups
     const int algo = env_int("MAREX_THR_ALGO", 0);   // 0 auto, 1 force sliding histograms
     const int p = ws / 2;
-    const bool band_ok = (1 << shift) <= 64 && p <= 3 && max_bucket > 0 && (int64_t)max_bucket * wd <= 65535;
+    const bool band_ok = (1 << shift) <= 64 && p <= 3 && max_bucket > 0 && (int64_t)max_bucket * wd * ws * ws <= 65535;
     if (algo != 1 && band_ok) {
-        const int TR = (ny > 0 && p > 0) ? 16 : 1, TC = 256 / TR;
+        // tile: 16x16 cells / 256 threads, or 32x32 / 1024 threads (less halo redundancy, more output lanes)
+        const bool big = (ny > 0 && p > 0) && env_int("MAREX_THR_TILE", 16) == 32 && (row1 - row0) >= 16 && nx >= 16;
+        const int NT = big ? 1024 : 256;
+        const int TR = (ny > 0 && p > 0) ? (big ? 32 : 16) : 1, TC = NT / TR;
         const int OR = TR - 2 * p, OC = TC - 2 * p;
-        int Dd = env_int("MAREX_THR_DD", TB_DMAX);
-        if (Dd < 1 || Dd > TB_DMAX) Dd = TB_DMAX;
+        int Dd = env_int("MAREX_THR_DD", big ? 16 : TB_DMAX);
+        if (Dd < 1 || Dd > (big ? 16 : TB_DMAX)) Dd = big ? 16 : TB_DMAX;
         const int tiles_x = (nx + OC - 1) / OC, tiles_y = (row1 - row0 + OR - 1) / OR;
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((NDOY + Dd - 1) / Dd));
-#define MAREX_BAND_ARGS bins, (long)T_out, (long)C, ny, nx, row0, row1, tiles_x, Dd, shift, env_int("MAREX_THR_EXACT_PATH", 0), doy_start, first_anom, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats
+#define MAREX_BAND_ARGS bins, (long)T_out, (long)C, ny, nx, row0, row1, tiles_x, Dd, shift, env_int("MAREX_THR_EXACT_PATH", 0), env_int("MAREX_THR_ABLATE", 0), doy_start, first_anom, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats
         {
             LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
             if (TR == 1)
-                hipLaunchKernelGGL((k_thr_band<0, 256>), grid, dim3(256), 0, ctx->stream, MAREX_BAND_ARGS);
+                hipLaunchKernelGGL((k_thr_band<0, 256, 256>), grid, dim3(256), 0, ctx->stream, MAREX_BAND_ARGS);
+            else if (big && p == 1)
+                hipLaunchKernelGGL((k_thr_band<1, 32, 1024>), grid, dim3(1024), 0, ctx->stream, MAREX_BAND_ARGS);
+            else if (big && p == 2)
+                hipLaunchKernelGGL((k_thr_band<2, 32, 1024>), grid, dim3(1024), 0, ctx->stream, MAREX_BAND_ARGS);
+            else if (big)
+                hipLaunchKernelGGL((k_thr_band<3, 32, 1024>), grid, dim3(1024), 0, ctx->stream, MAREX_BAND_ARGS);
             else if (p == 1)
-                hipLaunchKernelGGL((k_thr_band<1, 16>), grid, dim3(256), 0, ctx->stream, MAREX_BAND_ARGS);
+                hipLaunchKernelGGL((k_thr_band<1, 16, 256>), grid, dim3(256), 0, ctx->stream, MAREX_BAND_ARGS);
             else if (p == 2)
-                hipLaunchKernelGGL((k_thr_band<2, 16>), grid, dim3(256), 0, ctx->stream, MAREX_BAND_ARGS);
+                hipLaunchKernelGGL((k_thr_band<2, 16, 256>), grid, dim3(256), 0, ctx->stream, MAREX_BAND_ARGS);
             else
-                hipLaunchKernelGGL((k_thr_band<3, 16>), grid, dim3(256), 0, ctx->stream, MAREX_BAND_ARGS);
+                hipLaunchKernelGGL((k_thr_band<3, 16, 256>), grid, dim3(256), 0, ctx->stream, MAREX_BAND_ARGS);
         }
 #undef MAREX_BAND_ARGS
         HIP_TRY(ctx, hipGetLastError());

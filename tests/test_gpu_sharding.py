@@ -1,0 +1,67 @@
+"""GPU: latitude-band shards with overlap rows, processed one after the other on one device, stitch to
+exactly the unsharded result (SURVEY.md 8e "testability"); plus size-independent properties on a larger field."""
+import numpy as np
+import pytest
+import torch
+
+from marex_amd import binning, calendar, synth
+from marex_amd.dist import plan_shards, stitch_cells
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(hot, tm, cal, dcal, bt, ny_global, nx, shard=None, W=5):
+    if shard is None:
+        tab = synth.make_tables(tm, ny_global, nx)
+        x = hot.synth_field(tab)
+        r = hot.shifting_hobday(x, dcal, W=W, S=21, bins=bt, q=0.95, wd=11, ws=5, ny=ny_global, nx=nx)
+    else:
+        tab = synth.make_tables(tm, shard.ny_in, nx, lat_range=(shard.in0, shard.in1, ny_global))
+        x = hot.synth_field(tab, cell_base=shard.cell_base)
+        own = (shard.own0 - shard.in0, shard.own1 - shard.in0)
+        r = hot.shifting_hobday(x, dcal, W=W, S=21, bins=bt, q=0.95, wd=11, ws=5, ny=shard.ny_in, nx=nx, own_rows=own)
+    hot.sync()
+    return {k: r[k].cpu().numpy() for k in ("dat_anomaly", "extreme_events", "thr_doy_major", "mask")}, int(r["n_true"].item())
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_band_shards_stitch_bit_identical(hot, world):
+    ny, nx, W = 40, 48, 5
+    tm = calendar.daily_time_axis("2010-01-01", 10 * 365 + 3)
+    cal = calendar.build_calendar(tm, window_year_baseline=W)
+    dcal = hot.upload_calendar(cal)
+    bt = binning.hobday_bins()
+    full, n_full = _run(hot, tm, cal, dcal, bt, ny, nx)
+    shards = plan_shards(ny, nx, world, 2)
+    parts, n_sum = [], 0
+    for sh in shards:
+        p, n = _run(hot, tm, cal, dcal, bt, ny, nx, shard=sh)
+        parts.append(p)
+        n_sum += n
+    for key in ("dat_anomaly", "extreme_events", "thr_doy_major", "mask"):
+        got = stitch_cells([p[key] for p in parts], shards)
+        assert np.array_equal(got, full[key], equal_nan=True), key
+    assert n_sum == n_full == int(full["extreme_events"].sum())  # the kernel counts owned cells only
+
+
+def test_full_width_properties(hot):
+    """1440-wide rows (the benchmark grid's width) x 48 rows: determinism, land handling, frequency, counters."""
+    ny, nx, W = 48, 1440, 5
+    tm = calendar.daily_time_axis("2015-01-01", 3652)
+    cal = calendar.build_calendar(tm, window_year_baseline=W)
+    dcal = hot.upload_calendar(cal)
+    bt = binning.hobday_bins()
+    a, na = _run(hot, tm, cal, dcal, bt, ny, nx)
+    b, nb_ = _run(hot, tm, cal, dcal, bt, ny, nx)
+    for key in a:
+        assert np.array_equal(a[key], b[key], equal_nan=True)  # idempotent / deterministic
+    ocean = a["mask"].astype(bool)
+    assert 0.5 < ocean.mean() < 0.9
+    assert np.isnan(a["dat_anomaly"][:, ~ocean]).all() and not a["extreme_events"][:, ~ocean].any()
+    assert np.isnan(a["thr_doy_major"][:, ~ocean]).all() and (a["thr_doy_major"][:, ocean] >= bt.lower_bound).all()
+    freq = a["extreme_events"][:, ocean].mean()
+    assert abs(freq - 0.05) < 0.01
+    assert na == nb_ == int(a["extreme_events"].sum())
+    # mask == anomaly >= threshold[doy] recomputed on the host from the device outputs
+    exp = a["dat_anomaly"] >= a["thr_doy_major"][cal.doy_out.astype(np.int64) - 1]
+    assert np.array_equal(a["extreme_events"].astype(bool), exp)

@@ -115,14 +115,15 @@ def test_threshold_kernel_variants(hot, monkeypatch):
     """Band algorithm with other day-block lengths and the sliding-histogram kernel (16/32-bit counters,
     other segment widths) all give the same bits as the default."""
     envs = (
-        {"MAREX_THR_DD": "1"}, {"MAREX_THR_DD": "5"}, {"MAREX_THR_DD": "32"}, {"MAREX_THR_EXACT_PATH": "1"},
+        {"MAREX_THR_DD": "1"}, {"MAREX_THR_DD": "5"}, {"MAREX_THR_DD": "32"},
+        {"MAREX_THR_EXACT_PATH": "1"}, {"MAREX_THR_TILE": "32"}, {"MAREX_THR_TILE": "32", "MAREX_THR_EXACT_PATH": "1"},
         {"MAREX_THR_ALGO": "1"}, {"MAREX_THR_ALGO": "1", "MAREX_THR_U32": "1"},
         {"MAREX_THR_ALGO": "1", "MAREX_THR_NW": "5"}, {"MAREX_THR_ALGO": "1", "MAREX_THR_NW": "64", "MAREX_THR_U32": "1"},
     )
     for env in envs:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        r = run_case(hot, "2003-01-01", 9 * 365 + 2, 7, 21, 4, 21, 11, 5)
+        r = run_case(hot, "2003-01-01", 9 * 365 + 2, 19, 37, 4, 21, 11, 5)
         check_all(*r)
         for k in env:
             monkeypatch.delenv(k)
