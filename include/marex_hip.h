@@ -76,10 +76,11 @@ int marex_synth_sst_f32(marex_ctx* ctx, const float* mean, const float* amp, con
  * rolling_climatology (1511-1688), _compute_anomaly_shifting_baseline (1819-1850), the year trim
  * (615-641) and the np.digitize step of _compute_histogram_quantile_2d (2622-2631).
  *
- *  tindex[n_cal_years*366]  timestep of (calendar-year index, dayofyear-1) or -1
- *  out_index[T]             output row of timestep t or -1 (trimmed)
- *  rowb_index[T]            row of timestep t in the dayofyear-sorted bin matrix or -1
- *  first_valid_year         first calendar-year index that gets a climatology (= W)
+ *  year_plan[n_cal_years*366][4]  int32 {timestep, output row, bin-matrix row, 0} of (calendar-year index,
+ *                           dayofyear-1); -1 where absent / not an output (rows of the first W years are
+ *                           trimmed: detect.py:638-641).  16-byte aligned.  Built on the host from dt.year /
+ *                           dt.dayofyear (marex_amd/calendar.py); bin-matrix rows are the kept timesteps sorted
+ *                           by (dayofyear, time).
  *  write_clim               0: out = x - clim (anomaly); 1: out = clim (rolling_climatology API)
  *  edges[nb+1], bins        bin table and output bin matrix, uint16, T_out rows (both may be NULL: no binning).
  *                           BIN MATRIX LAYOUT (all entry points): blocks of 16 consecutive cells; element
@@ -89,8 +90,7 @@ int marex_synth_sst_f32(marex_ctx* ctx, const float* mean, const float* amp, con
  *  invalid_count[C]         number of non-finite x[t, c] over t; must be zeroed by the caller (may be NULL)
  */
 int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
-                                const int32_t* tindex, int n_cal_years, int first_valid_year,
-                                const int32_t* out_index, const int32_t* rowb_index, int W, int S,
+                                const int32_t* year_plan, int n_cal_years, int W, int S,
                                 int write_clim, const float* edges, int nb, int64_t T_out, float* out,
                                 uint16_t* bins, uint8_t* mask, int32_t* invalid_count);
 

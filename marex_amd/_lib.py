@@ -36,7 +36,7 @@ PROTOTYPES = {
     "marex_synth_sst_f32": (_i32, [_p, _p, _p, _p, _p, _p, _p, _u64, _i64, _i64, _i64, _p]),
     "marex_shifting_baseline_f32": (
         _i32,
-        [_p, _p, _i64, _i64, _p, _i32, _i32, _p, _p, _i32, _i32, _i32, _p, _i32, _i64, _p, _p, _p, _p],
+        [_p, _p, _i64, _i64, _p, _i32, _i32, _i32, _i32, _p, _i32, _i64, _p, _p, _p, _p],
     ),
     "marex_hobday_thresholds_f32": (
         _i32,

@@ -83,6 +83,18 @@ class CalendarPlan:
     def n_years_present(self) -> int:
         return int(np.unique(self.year).size)
 
+    def year_plan(self) -> np.ndarray:
+        """``[n_cal_years, 366, 4]`` int32 ``{timestep, output row, bin-matrix row, 0}`` (-1 = none): everything the
+        shifting-baseline kernel needs to know about one (calendar year, dayofyear) in a single 16-byte load."""
+        plan = np.full((self.n_cal_years, N_DOY, 4), -1, dtype=np.int32)
+        plan[..., 3] = 0
+        t = self.tindex
+        have = t >= 0
+        plan[..., 0] = t
+        plan[..., 1][have] = self.out_index[t[have]]
+        plan[..., 2][have] = self.rowb_index[t[have]]
+        return plan
+
 
 def build_calendar(time=None, *, year=None, doy=None, window_year_baseline: Optional[int] = None) -> CalendarPlan:
     """Build the tables for a time axis.

@@ -86,6 +86,11 @@ static void drain_timers(marex_ctx* ctx) {
     ctx->pending.clear();
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
 extern "C" int marex_abi_version(void) { return MAREX_ABI_VERSION; }
 
 extern "C" int marex_create(int device, marex_ctx** out) {
@@ -262,16 +267,15 @@ extern "C" int marex_synth_sst_f32(marex_ctx* ctx, const float* mean, const floa
 // is read by ceil((D+S-1)/D) chunks; blocks of one cell block are placed on one XCD so that those
 // re-reads are L2 / Infinity-Cache hits and HBM sees every byte of x about once.
 // ------------------------------------------------------------------------------------------------
-template <int D, int SCAP, bool SEXACT>
+template <int D, int SCAP, bool SEXACT, int WCAP>
 __global__ void __launch_bounds__(256)
-k_shifting(const float* __restrict__ x, long T, long C, const int* __restrict__ tindex, int n_cal,
-           int first_valid, const int* __restrict__ out_index, const int* __restrict__ rowb_index, int W,
+k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__ year_plan, int n_cal, int W,
            int S_rt, int write_clim, const float* __restrict__ edges, int nb, long T_out, float* __restrict__ out,
            unsigned short* __restrict__ bins, unsigned char* __restrict__ mask, int* __restrict__ invalid_count,
-           int ncb, int nchunks) {
+           int ncb, int nchunks, int ablate) {
     extern __shared__ float lds[];
-    float* ring = lds;                  // [D][W][256]
-    float* e = lds + (size_t)D * W * 256;  // [nb+1] when binning
+    float* ring = lds;                        // [D][WCAP][256]; slots W..WCAP-1 hold +0.0 (neutral in the sum)
+    float* e = lds + (size_t)D * WCAP * 256;  // [nb+1] when binning
 
     int cb, chunk;
     if (!xcd_swizzle(blockIdx.x, ncb, nchunks, cb, chunk)) return;
@@ -282,10 +286,9 @@ k_shifting(const float* __restrict__ x, long T, long C, const int* __restrict__ 
     const int lo = S / 2;
     const float Sf = (float)S;
     const int d0 = chunk * D;
-    const int Dv = (NDOY - d0) < D ? (NDOY - d0) : D;
     const bool do_bins = bins != nullptr;
 
-    for (int i = tid; i < D * W * 256; i += 256) ring[i] = nan_f();
+    for (int i = tid; i < D * WCAP * 256; i += 256) ring[i] = ((i >> 8) % WCAP) < W ? nan_f() : 0.f;
     if (do_bins)
         for (int i = tid; i <= nb; i += 256) e[i] = edges[i];
     __syncthreads();
@@ -295,212 +298,191 @@ k_shifting(const float* __restrict__ x, long T, long C, const int* __restrict__ 
     int n_invalid = 0;
     if (chunk == 0 && mask && active) mask[c] = finite_f(x[c]) ? 1 : 0;
 
-    // one (dayofyear i, year y) element: climatology from the ring, anomaly, bin, then push s into the ring
-    auto emit = [&](int i, int y, int t, float xc, float s) {
-        float* col = ring + (size_t)i * W * 256 + tid;
-        const int slot0 = y % W;
-        if (t >= 0) {
+    // One (dayofyear i, year y) element: climatology from the ring, anomaly, bin, then push s into the ring.
+    // pl = {timestep, output row, bin-matrix row} (-1: none).  The ring is read with NO predicates: the slots
+    // of years y-W .. y-1 in ascending order (slot0, slot0+1, ... mod W), then the +0.0 pad slots.
+    auto emit = [&](int i, int slot0, const int4 pl, float xc, float s) {
+        if (ablate & 1) {  // timing only: keep the inputs alive, skip climatology / anomaly / bins / stores
+            if (xc + s == 12345.678f && active) out[c] = xc;
+            return;
+        }
+        float* col = ring + (size_t)i * WCAP * 256 + tid;
+        if (pl.x >= 0) {
             if (!finite_f(xc)) ++n_invalid;
-            if (y >= first_valid) {
-                const int oi = out_index[t];
-                if (oi >= 0) {
-                    float clim = nan_f();
-                    if (write_clim || xc == xc) {
-                        // years y-W .. y-1 in ascending order = slots slot0, slot0+1, ... (mod W)
-                        float acc = 0.f;
-                        int sl = slot0;
-                        for (int j = 0; j < W; ++j) {
-                            acc += col[sl * 256];
-                            sl = (sl + 1 == W) ? 0 : sl + 1;
+            if (pl.y >= 0) {
+                float clim = nan_f();
+                if (write_clim || xc == xc) {
+                    float rv[WCAP];
+                    float acc = 0.f;
+                    int n = W;
+                    if (ablate & 8) {
+                        acc = s;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < WCAP; ++j) {
+                            int sl = slot0 + j;
+                            sl = sl >= W ? sl - W : sl;
+                            sl = j < W ? sl : j;
+                            rv[j] = col[sl * 256];
                         }
-                        int n = W;
-                        if (!(acc == acc)) {  // a NaN term: redo as nanmean
+#pragma unroll
+                        for (int j = 0; j < WCAP; ++j) acc += rv[j];
+                        if (!(acc == acc)) {  // a NaN term: redo as nanmean (rare: leap day, first days, gaps)
                             acc = 0.f;
                             n = 0;
-                            sl = slot0;
                             for (int j = 0; j < W; ++j) {
-                                float v = col[sl * 256];
+                                int sl = slot0 + j;
+                                sl = sl >= W ? sl - W : sl;
+                                const float v = col[sl * 256];
                                 if (v == v) {
                                     acc += v;
                                     ++n;
                                 }
-                                sl = (sl + 1 == W) ? 0 : sl + 1;
                             }
                         }
-                        clim = acc / (float)n;  // n == 0 -> 0/0 = NaN
                     }
-                    if (active) {
-                        const float a = xc - clim;
-                        out[(size_t)oi * C + c] = write_clim ? clim : a;
-                        if (do_bins) {
-                            const int rb = rowb_index[t];
-                            bins[bins_index(rb, c, T_out)] = (unsigned short)digitize_bin(a, e, nb, inv_width);
-                        }
-                    }
+                    clim = (ablate & 16) ? acc : acc / (float)n;  // n == 0 -> 0/0 = NaN
+                }
+                if (active) {
+                    const float a = xc - clim;
+                    if (!(ablate & 64)) out[(size_t)pl.y * C + c] = write_clim ? clim : a;
+                    if (do_bins && !(ablate & 32))
+                        bins[bins_index(pl.z, c, T_out)] = (unsigned short)digitize_bin(a, e, nb, inv_width);
+                    if ((ablate & 96) == 96 && a == 12345.678f) out[c] = a;
                 }
             }
         }
-        col[slot0 * 256] = (t >= 0) ? s : nan_f();
+        col[slot0 * 256] = (pl.x >= 0) ? s : nan_f();
     };
 
     // Inactive lanes (beyond C) stream the last cell instead of being masked off: loads stay unconditional
     // and uniform in control flow; only the stores are guarded by `active`.
     const unsigned cidx = active ? (unsigned)c : (unsigned)(C - 1);
-    float xw[D + SCAP - 1];
+    constexpr int NL = D + SCAP - 1;
+    float xw[NL];
     for (int y = 0; y < n_cal; ++y) {
-        const int* trow = tindex + (size_t)y * NDOY + d0;
-        int tt[D];
+        // this year's D plan entries (dayofyears past 366 in the last chunk count as absent)
+        int4 pl[D];
         bool fast = true, any = false;
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            tt[i] = (i < Dv) ? trow[i] : -1;
-            if (i < Dv) {
-                any |= tt[i] >= 0;
-                fast &= (tt[i] >= 0) && (tt[i] == tt[0] + i);
-            }
+            pl[i] = (d0 + i < NDOY) ? year_plan[(size_t)y * NDOY + d0 + i] : make_int4(-1, -1, -1, 0);
+            any |= pl[i].x >= 0;
+            fast &= (pl[i].x >= 0) && (pl[i].x == pl[0].x + i);
         }
         if (!any && y < W) continue;  // nothing to read, and the ring slot of this year still holds its initial NaN
-        if (fast) {
-            const long r0 = (long)tt[0] - lo;
-            const int nload = Dv + S - 1;
-            if (r0 >= 0 && r0 + nload <= T) {  // whole batch inside the series: no per-row checks
+        const int slot0 = y % W;
+        const long r0 = (long)pl[0].x - lo;
+        if (fast && SEXACT && r0 >= 0 && r0 + NL <= T) {
+            // D consecutive timesteps, whole batch inside the series: NL unconditional row loads, no predicates
+            if (ablate & 4) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) xw[j] = (float)(j + y) * 0.25f;
+            } else {
                 const float* rowp = x + (size_t)r0 * C;
 #pragma unroll
-                for (int j = 0; j < D + SCAP - 1; ++j) {
-                    if (j < nload) {
-                        xw[j] = rowp[cidx];
-                        rowp += C;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < D + SCAP - 1; ++j) {
-                    if (j < nload) {
-                        const long row = r0 + j;
-                        xw[j] = (row >= 0 && row < T) ? x[(size_t)row * C + cidx] : nan_f();
-                    }
+                for (int j = 0; j < NL; ++j) {
+                    xw[j] = rowp[cidx];
+                    rowp += C;
                 }
             }
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                if (i < Dv) {
-                    float acc = xw[i];
-                    float xc = (lo == 0) ? xw[i] : 0.f;
+                float acc = xw[i];
+                if (ablate & 2) {
+                    acc = xw[i] + xw[NL - 1];
+                } else {
 #pragma unroll
-                    for (int k = 1; k < SCAP; ++k) {
-                        if (k < S) {
-                            acc += xw[i + k];
-                            if (k == lo) xc = xw[i + k];
-                        }
-                    }
-                    emit(i, y, tt[i], xc, acc / Sf);
+                    for (int k = 1; k < SCAP; ++k) acc += xw[i + k];
                 }
+                emit(i, slot0, pl[i], xw[i + SCAP / 2], acc / Sf);
             }
         } else {
+            // generic path: every present dayofyear loads its own S rows with range checks (series ends,
+            // calendar gaps, leap day, runtime S)
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                if (i < Dv) {
-                    float xc = nan_f(), s = nan_f();
-                    if (tt[i] >= 0) {
-                        const long r0 = (long)tt[i] - lo;
-#pragma unroll
-                        for (int k = 0; k < SCAP; ++k) {
-                            if (k < S) {
-                                const long row = r0 + k;
-                                xw[k] = (row >= 0 && row < T) ? x[(size_t)row * C + cidx] : nan_f();
-                            }
-                        }
-                        float acc = xw[0];
-                        xc = (lo == 0) ? xw[0] : 0.f;
-#pragma unroll
-                        for (int k = 1; k < SCAP; ++k) {
-                            if (k < S) {
-                                acc += xw[k];
-                                if (k == lo) xc = xw[k];
-                            }
-                        }
-                        s = acc / Sf;
+                float xc = nan_f(), sm = nan_f();
+                if (pl[i].x >= 0) {
+                    const long q0 = (long)pl[i].x - lo;
+                    float acc = 0.f;
+                    for (int k = 0; k < S; ++k) {
+                        const long row = q0 + k;
+                        const float v = (row >= 0 && row < T) ? x[(size_t)row * C + cidx] : nan_f();
+                        acc = (k == 0) ? v : acc + v;
+                        if (k == lo) xc = v;
                     }
-                    emit(i, y, tt[i], xc, s);
+                    sm = acc / Sf;
                 }
+                emit(i, slot0, pl[i], xc, sm);
             }
         }
     }
     if (invalid_count && active && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
 }
 
-template <int D, int SCAP, bool SEXACT>
-static int launch_shifting(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* tindex, int n_cal,
-                           int first_valid, const int32_t* out_index, const int32_t* rowb_index, int W, int S,
-                           int write_clim, const float* edges, int nb, int64_t T_out, float* out, uint16_t* bins,
-                           uint8_t* mask, int32_t* invalid_count) {
-    const int ncb = (int)((C + 255) / 256);
+struct ShiftArgs {
+    const float* x;
+    int64_t T, C;
+    const int4* year_plan;
+    int n_cal;
+    int W, S, write_clim;
+    const float* edges;
+    int nb;
+    int64_t T_out;
+    float* out;
+    uint16_t* bins;
+    uint8_t* mask;
+    int32_t* invalid_count;
+};
+
+template <int D, int SCAP, bool SEXACT, int WCAP>
+static int launch_shifting(marex_ctx* ctx, const ShiftArgs& a) {
+    const int ncb = (int)((a.C + 255) / 256);
     const int nchunks = (NDOY + D - 1) / D;
-    const size_t lds = ((size_t)D * W * 256 + (bins ? (size_t)nb + 1 : 0)) * sizeof(float);
-    auto kern = k_shifting<D, SCAP, SEXACT>;
+    const size_t lds = ((size_t)D * WCAP * 256 + (a.bins ? (size_t)a.nb + 1 : 0)) * sizeof(float);
+    if (lds > 80 * 1024) return fail(ctx, -4, "marex_shifting_baseline_f32: window_year_baseline=%d needs more than 80 KiB of LDS", a.W);
+    auto kern = k_shifting<D, SCAP, SEXACT, WCAP>;
     if (lds > 48 * 1024)
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         LaunchTimer lt(ctx, MAREX_K_SHIFTING);
-        hipLaunchKernelGGL(kern, dim3(xcd_grid(ncb, nchunks)), dim3(256), lds, ctx->stream, x, (long)T, (long)C,
-                           tindex, n_cal, first_valid, out_index, rowb_index, W, S, write_clim, edges, nb, (long)T_out,
-                           out, bins, mask, invalid_count, ncb, nchunks);
+        hipLaunchKernelGGL(kern, dim3(xcd_grid(ncb, nchunks)), dim3(256), lds, ctx->stream, a.x, (long)a.T, (long)a.C,
+                           a.year_plan, a.n_cal, a.W, a.S, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins,
+                           a.mask, a.invalid_count, ncb, nchunks, env_int("MAREX_SHIFT_ABLATE", 0));
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 
-template <int SCAP, bool SEXACT>
-static int dispatch_shifting_D(int D, marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* tindex,
-                               int n_cal, int first_valid, const int32_t* out_index, const int32_t* rowb_index,
-                               int W, int S, int write_clim, const float* edges, int nb, int64_t T_out,
-                               float* out, uint16_t* bins, uint8_t* mask, int32_t* invalid_count) {
-#define MAREX_ARGS ctx, x, T, C, tindex, n_cal, first_valid, out_index, rowb_index, W, S, write_clim, edges, nb, T_out, out, bins, mask, invalid_count
-    switch (D) {
-        case 8: return launch_shifting<8, SCAP, SEXACT>(MAREX_ARGS);
-        case 4: return launch_shifting<4, SCAP, SEXACT>(MAREX_ARGS);
-        case 2: return launch_shifting<2, SCAP, SEXACT>(MAREX_ARGS);
-        default: return launch_shifting<1, SCAP, SEXACT>(MAREX_ARGS);
-    }
-#undef MAREX_ARGS
-}
-
-static int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
+template <int D, int WCAP>
+static int dispatch_shifting_S(marex_ctx* ctx, const ShiftArgs& a) {
+    if (a.S == 21) return launch_shifting<D, 21, true, WCAP>(ctx, a);
+    return launch_shifting<D, 1, false, WCAP>(ctx, a);  // any other smoothing width: generic row loop
 }
 
 extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
-                                           const int32_t* tindex, int n_cal_years, int first_valid_year,
-                                           const int32_t* out_index, const int32_t* rowb_index, int W, int S,
+                                           const int32_t* year_plan, int n_cal_years, int W, int S,
                                            int write_clim, const float* edges, int nb, int64_t T_out, float* out,
                                            uint16_t* bins, uint8_t* mask, int32_t* invalid_count) {
     if (!ctx) return -1;
-    if (!x || !tindex || !out_index || !out || T <= 0 || C <= 0 || n_cal_years <= 0)
+    if (!x || !year_plan || !out || T <= 0 || C <= 0 || n_cal_years <= 0)
         return fail(ctx, -1, "marex_shifting_baseline_f32: null pointer or empty shape");
+    if (((uintptr_t)year_plan & 15) != 0) return fail(ctx, -1, "marex_shifting_baseline_f32: year_plan must be 16-byte aligned");
     if (W < 1 || S < 1) return fail(ctx, -1, "marex_shifting_baseline_f32: W and S must be >= 1");
-    if (S > 128) return fail(ctx, -4, "marex_shifting_baseline_f32: smooth_days_baseline > 128 is not supported");
-    if (bins && (!edges || !rowb_index || nb < 4 || nb > 65534 || T_out <= 0))
-        return fail(ctx, -1, "marex_shifting_baseline_f32: binning needs edges, rowb_index, T_out and 4 <= nb <= 65534");
+    if (S > T) S = (int)T + 1;  // every window leaves the series: all-NaN smoothing either way
+    if (W > 64) return fail(ctx, -4, "marex_shifting_baseline_f32: window_year_baseline > 64 is not supported");
+    if (bins && (!edges || nb < 4 || nb > 65534 || T_out <= 0))
+        return fail(ctx, -1, "marex_shifting_baseline_f32: binning needs edges, T_out and 4 <= nb <= 65534");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // largest dayofyear chunk whose LDS ring leaves room for two workgroups per CU
-    const size_t budget = 72 * 1024, extra = bins ? ((size_t)nb + 1) * 4 : 0;
-    int D = env_int("MAREX_SHIFT_D", 0);
-    if (D != 1 && D != 2 && D != 4 && D != 8) {
-        // 8 dayofyears per workgroup (3.5 row loads per output) while three workgroups still fit a CU,
-        // otherwise the largest chunk that leaves room for two
-        D = ((size_t)8 * W * 1024 + extra <= 48 * 1024) ? 8 : 4;
-        while (D > 1 && (size_t)D * W * 1024 + extra > budget) D >>= 1;
-    }
-    if ((size_t)D * W * 1024 + extra > 80 * 1024)
-        return fail(ctx, -4, "marex_shifting_baseline_f32: window_year_baseline=%d needs more than 80 KiB of LDS", W);
-#define MAREX_ARGS D, ctx, x, T, C, tindex, n_cal_years, first_valid_year, out_index, rowb_index, W, S, write_clim, edges, nb, T_out, out, bins, mask, invalid_count
-    if (S == 21) return dispatch_shifting_D<21, true>(MAREX_ARGS);
-    if (S <= 8) return dispatch_shifting_D<8, false>(MAREX_ARGS);
-    if (S <= 32) return dispatch_shifting_D<32, false>(MAREX_ARGS);
-    if (S <= 64) return dispatch_shifting_D<64, false>(MAREX_ARGS);
-    return dispatch_shifting_D<128, false>(MAREX_ARGS);
-#undef MAREX_ARGS
+    const ShiftArgs a{x, T, C, reinterpret_cast<const int4*>(year_plan), n_cal_years, W, S, write_clim,
+                      edges, nb, T_out, out, bins, mask, invalid_count};
+    // 4 dayofyears per workgroup (6 row loads per output) while the padded W-year LDS ring leaves room for two
+    // workgroups per CU, otherwise one dayofyear
+    const int forceD = env_int("MAREX_SHIFT_D", 0);
+    if (W <= 8) return forceD == 1 ? dispatch_shifting_S<1, 8>(ctx, a) : dispatch_shifting_S<4, 8>(ctx, a);
+    if (W <= 16) return forceD == 1 ? dispatch_shifting_S<1, 16>(ctx, a) : dispatch_shifting_S<4, 16>(ctx, a);
+    return dispatch_shifting_S<1, 64>(ctx, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -31,6 +31,7 @@ class DeviceCalendar:
     """Calendar tables resident on the device."""
 
     tindex: torch.Tensor
+    year_plan: torch.Tensor
     out_index: torch.Tensor
     rowb_index: torch.Tensor
     doy_start: torch.Tensor
@@ -74,6 +75,7 @@ class HotPath:
     def upload_calendar(self, cal: CalendarPlan) -> DeviceCalendar:
         return DeviceCalendar(
             tindex=self._dev(cal.tindex, np.int32),
+            year_plan=self._dev(cal.year_plan(), np.int32),
             out_index=self._dev(cal.out_index, np.int32),
             rowb_index=self._dev(cal.rowb_index, np.int32),
             doy_start=self._dev(cal.doy_start, np.int32),
@@ -157,8 +159,8 @@ class HotPath:
             edges = binsb = None
             e_ptr, b_ptr, nb = None, None, 0
         rc = self.lib.marex_shifting_baseline_f32(
-            self.ctx.handle, x.data_ptr(), T, Cn, dcal.tindex.data_ptr(), cal.n_cal_years, int(W),
-            dcal.out_index.data_ptr(), dcal.rowb_index.data_ptr(), int(W), int(S), int(write_clim),
+            self.ctx.handle, x.data_ptr(), T, Cn, dcal.year_plan.data_ptr(), cal.n_cal_years,
+            int(W), int(S), int(write_clim),
             e_ptr, nb, T_out, out.data_ptr(), b_ptr, mask.data_ptr(), invalid.data_ptr(),
         )
         self.ctx.check(rc, "marex_shifting_baseline_f32")
