@@ -275,7 +275,8 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
            int ncb, int nchunks, int ablate) {
     extern __shared__ float lds[];
     float* ring = lds;                        // [D][WCAP][256]; slots W..WCAP-1 hold +0.0 (neutral in the sum)
-    float* e = lds + (size_t)D * WCAP * 256;  // [nb+1] when binning
+    int4* lplan = reinterpret_cast<int4*>(lds + (size_t)D * WCAP * 256);  // [n_cal][D] this chunk's plan column
+    float* e = reinterpret_cast<float*>(lplan + (size_t)n_cal * D);      // [nb+1] when binning
 
     int cb, chunk;
     if (!xcd_swizzle(blockIdx.x, ncb, nchunks, cb, chunk)) return;
@@ -289,6 +290,12 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
     const bool do_bins = bins != nullptr;
 
     for (int i = tid; i < D * WCAP * 256; i += 256) ring[i] = ((i >> 8) % WCAP) < W ? nan_f() : 0.f;
+    // the chunk's {timestep, output row, bin row} entries of every year, staged once: the year loop then reads
+    // them from LDS instead of waiting on a scalar global load per year (dayofyears past 366 count as absent)
+    for (int i = tid; i < n_cal * D; i += 256) {
+        const int y = i / D, k = i - y * D;
+        lplan[i] = (d0 + k < NDOY) ? year_plan[(size_t)y * NDOY + d0 + k] : make_int4(-1, -1, -1, 0);
+    }
     if (do_bins)
         for (int i = tid; i <= nb; i += 256) e[i] = edges[i];
     __syncthreads();
@@ -366,7 +373,7 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
         bool fast = true, any = false;
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            pl[i] = (d0 + i < NDOY) ? year_plan[(size_t)y * NDOY + d0 + i] : make_int4(-1, -1, -1, 0);
+            pl[i] = lplan[y * D + i];
             any |= pl[i].x >= 0;
             fast &= (pl[i].x >= 0) && (pl[i].x == pl[0].x + i);
         }
@@ -440,7 +447,7 @@ template <int D, int SCAP, bool SEXACT, int WCAP>
 static int launch_shifting(marex_ctx* ctx, const ShiftArgs& a) {
     const int ncb = (int)((a.C + 255) / 256);
     const int nchunks = (NDOY + D - 1) / D;
-    const size_t lds = ((size_t)D * WCAP * 256 + (a.bins ? (size_t)a.nb + 1 : 0)) * sizeof(float);
+    const size_t lds = ((size_t)D * WCAP * 256 + (a.bins ? (size_t)a.nb + 1 : 0)) * sizeof(float) + (size_t)a.n_cal * D * 16;
     if (lds > 80 * 1024) return fail(ctx, -4, "marex_shifting_baseline_f32: window_year_baseline=%d needs more than 80 KiB of LDS", a.W);
     auto kern = k_shifting<D, SCAP, SEXACT, WCAP>;
     if (lds > 48 * 1024)
