@@ -190,6 +190,14 @@ def main():
             "transpose": shard.cells_in * 8 * 366,
         }
         dom = max(kern, key=lambda k: kern[k][0])
+        # HBM bytes of the dominant kernel from the committed PMC passes of this same command (profiles/)
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", f"r01_{args.workload}_traffic.json")
+        kname = {"shifting": "k_shifting", "thresholds": "k_thr_band", "mask": "k_mask_ge", "transpose": "k_transpose"}[dom]
+        if world == 1 and os.path.exists(tfile):
+            for name, rec in json.load(open(tfile)).get("kernels", {}).items():
+                if name.startswith(kname):
+                    traffic = rec["hbm_bytes"]
         avg_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in kern.items()}
         achieved = per_kernel_alg[dom] / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] else 0.0
         out = {
@@ -221,7 +229,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "avg_launch_ms": avg_ms[dom],
                 "algorithmic_bytes_per_launch": per_kernel_alg[dom],
             },
