@@ -289,7 +289,8 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
     const int d0 = chunk * D;
     const bool do_bins = bins != nullptr;
 
-    for (int i = tid; i < D * WCAP * 256; i += 256) ring[i] = ((i >> 8) % WCAP) < W ? nan_f() : 0.f;
+    if (!(ablate & 128))
+        for (int i = tid; i < D * WCAP * 256; i += 256) ring[i] = ((i >> 8) % WCAP) < W ? nan_f() : 0.f;
     // the chunk's {timestep, output row, bin row} entries of every year, staged once: the year loop then reads
     // them from LDS instead of waiting on a scalar global load per year (dayofyears past 366 count as absent)
     for (int i = tid; i < n_cal * D; i += 256) {
@@ -304,6 +305,7 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
 
     int n_invalid = 0;
     if (chunk == 0 && mask && active) mask[c] = finite_f(x[c]) ? 1 : 0;
+    if (ablate & 256) return;  // timing only: launch + init
 
     // One (dayofyear i, year y) element: climatology from the ring, anomaly, bin, then push s into the ring.
     // pl = {timestep, output row, bin-matrix row} (-1: none).  The ring is read with NO predicates: the slots
