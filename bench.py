@@ -38,6 +38,11 @@ WORKLOADS = {
                      name="100yr-daily x 1440x90 band (1/8 of 0.25deg global), shifting_baseline(W=15,S=21)+hobday_extreme p95"),
     "tiny": dict(start="2015-01-01", T=3652, ny=48, nx=96, W=5, S=21, wd=11, ws=5, pct=95.0,
                  name="tiny plumbing case 10yr x 96x48"),
+    # BASELINE.json configs[2], the north-star shape: the WHOLE 100-yr field (151 GB of input) stays resident as 8
+    # overlapped latitude bands; every rank streams its 8/N bands through one reusable output workspace
+    # (314 GB of input + output do not fit 288 GB at once).  Strong scaling over N in {1,2,4,8}.
+    "cfg3": dict(start="1925-01-01", T=36500, ny=720, nx=1440, W=15, S=21, wd=11, ws=5, pct=95.0, bands=8,
+                 name="100yr-daily x 1440x720 (0.25deg) in 8 resident latitude bands, shifting_baseline(W=15,S=21)+hobday_extreme p95"),
 }
 
 
@@ -114,33 +119,48 @@ def main():
     wl = WORKLOADS[args.workload]
     T, nx, W = wl["T"], wl["nx"], wl["W"]
     halo = wl["ws"] // 2
-    shard = plan_shards(wl["ny"] * world, nx, world, halo)[rank]
+    nbands = wl.get("bands", 0)
+    if nbands:  # fixed global grid cut into `nbands` bands, strong scaling: rank r takes bands r, r+world, ...
+        if nbands % world:
+            raise SystemExit(f"--workload {args.workload} needs a GPU count that divides {nbands}")
+        all_shards = plan_shards(wl["ny"], nx, nbands, halo)
+        shards = [all_shards[i] for i in range(rank, nbands, world)]
+        ny_total = wl["ny"]
+    else:  # weak scaling: one band of wl["ny"] rows per rank
+        shards = [plan_shards(wl["ny"] * world, nx, world, halo)[rank]]
+        ny_total = wl["ny"] * world
+    shard = shards[0]
 
     hot = HotPath(local_rank)
     tm = calendar.daily_time_axis(wl["start"], T)
     cal = calendar.build_calendar(tm, window_year_baseline=W)
     dcal = hot.upload_calendar(cal)
     bt = binning.hobday_bins()
-    tab = synth.make_tables(tm, shard.ny_in, nx, args.seed, lat_range=(shard.in0, shard.in1, shard.ny_global))
-    x = hot.synth_field(tab, cell_base=shard.cell_base)  # [T, cells_in] resident in HBM before timing
-    own_rows = (shard.own0 - shard.in0, shard.own1 - shard.in0)
-    own = shard.own_cell_slice()
+    xs = []  # resident input, one [T, cells_in] tensor per band, generated on the device before timing
+    for sh in shards:
+        tab = synth.make_tables(tm, sh.ny_in, nx, args.seed, lat_range=(sh.in0, sh.in1, sh.ny_global))
+        xs.append(hot.synth_field(tab, cell_base=sh.cell_base))
 
     workspace = {}  # output buffers are allocated once and reused: no allocator traffic in the timed loop
 
     def step():
-        r = hot.shifting_hobday(
-            x, dcal, W=W, S=wl["S"], bins=bt, q=wl["pct"] / 100.0, wd=wl["wd"], ws=wl["ws"],
-            ny=shard.ny_in, nx=nx, own_rows=own_rows, workspace=workspace,
-        )
-        m = r["mask"][own].to(torch.int32)
-        inv = r["invalid_count"][own] * m
-        st = r["stats_dev"]
-        local = torch.stack([
-            m.sum().to(torch.int64), inv.sum().to(torch.int64), (inv > 0).sum().to(torch.int64),
-            r["n_true"][0], st[2].to(torch.int64), st[3].to(torch.int64),
-        ])
-        mx = inv.max().to(torch.int64).reshape(1)
+        local = torch.zeros(6, dtype=torch.int64, device=hot.device)
+        mx = torch.zeros(1, dtype=torch.int64, device=hot.device)
+        r = None
+        for sh, x in zip(shards, xs):
+            own = sh.own_cell_slice()
+            r = hot.shifting_hobday(
+                x, dcal, W=W, S=wl["S"], bins=bt, q=wl["pct"] / 100.0, wd=wl["wd"], ws=wl["ws"],
+                ny=sh.ny_in, nx=nx, own_rows=(sh.own0 - sh.in0, sh.own1 - sh.in0), workspace=workspace,
+            )
+            m = r["mask"][own].to(torch.int32)
+            inv = r["invalid_count"][own] * m
+            st = r["stats_dev"]
+            local += torch.stack([
+                m.sum().to(torch.int64), inv.sum().to(torch.int64), (inv > 0).sum().to(torch.int64),
+                r["n_true"][0], st[2].to(torch.int64), st[3].to(torch.int64),
+            ])
+            mx = torch.maximum(mx, inv.max().to(torch.int64).reshape(1))
         if world > 1:
             if backend != "nccl":  # gloo reduces host tensors
                 local, mx = local.cpu(), mx.cpu()
@@ -176,13 +196,14 @@ def main():
     summary["max_invalid"] = int(mx.item())
 
     if rank == 0:
-        C_own_total = wl["ny"] * world * nx
+        C_own_total = ny_total * nx
         units = T * C_own_total / 1e6  # Mcells*timesteps per step, whole job
         ms_step = dt / args.steps * 1e3
         value = units / (dt / args.steps)
         T_out = cal.T_out
-        b_alg_rank = algorithmic_bytes(T, T_out, shard.cells_own)
-        # dominant kernel and its own algorithmic bytes
+        cells_own_rank = sum(sh.cells_own for sh in shards)
+        b_alg_rank = algorithmic_bytes(T, T_out, cells_own_rank)
+        # dominant kernel and its own algorithmic bytes PER LAUNCH (one launch = one band)
         per_kernel_alg = {
             "shifting": shard.cells_in * (4 * T + 4 * T_out + 1),
             "thresholds": shard.cells_own * 4 * 366,
@@ -209,17 +230,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if nbands else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": wl["name"],
-                "per_gpu_grid": [wl["ny"], nx],
-                "global_grid": [wl["ny"] * world, nx],
+                "per_gpu_grid": [sum(sh.own1 - sh.own0 for sh in shards), nx],
+                "global_grid": [ny_total, nx],
+                "bands_per_gpu": len(shards),
                 "timesteps_in": T,
                 "timesteps_out": T_out,
-                "parallelism": f"lat-band x{world}, {halo} overlap rows, scalar all-reduce only",
+                "parallelism": f"lat-band x{max(world, nbands)}, {halo} overlap rows, scalar all-reduce only",
                 "summary": summary,
             },
             "roofline": {

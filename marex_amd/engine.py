@@ -58,11 +58,14 @@ class HotPath:
         (no allocator traffic in the steady state, outputs of the previous call are overwritten)."""
         if wsp is None:
             return torch.empty(shape, dtype=dtype, device=device)
-        t = wsp.get(name)
-        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            t = torch.empty(shape, dtype=dtype, device=device)
-            wsp[name] = t
-        return t
+        n = 1
+        for d in shape:
+            n *= int(d)
+        flat = wsp.get(name)
+        if flat is None or flat.dtype != dtype or flat.numel() < n:
+            flat = torch.empty((max(n, 1),), dtype=dtype, device=device)  # grows to the largest request, then stays
+            wsp[name] = flat
+        return flat[:n].view(shape)
 
     # ------------------------------------------------------------------ plumbing
     def _bind_stream(self) -> None:
