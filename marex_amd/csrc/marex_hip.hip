@@ -178,19 +178,46 @@ __device__ __forceinline__ size_t bins_index(long r, long c, long T_out) {
 // The guess assumes equal-width bins above edges[1]; the two correction loops make it exact for any
 // increasing table.
 __device__ __forceinline__ int digitize_bin(float v, const float* e, int nb, float inv_width) {
-    if (!(v == v)) return nb;
-    if (v >= e[nb]) return nb;
-    if (v < e[1]) return 0;
+    // straight-line: NaN / out-of-range inputs run through with a clamped guess and are fixed by selects at the end
     int k = 1 + (int)((v - e[1]) * inv_width);
     k = k < 1 ? 1 : (k > nb - 1 ? nb - 1 : k);
-    // the guess is off by at most one for equal-width tables: one branch-free correction, then verify
-    k += (v >= e[k + 1]) - (v < e[k]);
+    k += (v >= e[k + 1]) - (v < e[k]);  // the guess is off by at most one for equal-width tables
     k = k < 1 ? 1 : (k > nb - 1 ? nb - 1 : k);
-    if (!(v >= e[k] && v < e[k + 1])) {  // arbitrary increasing tables: walk (never taken for uniform bins)
+    const bool inside = v >= e[1] && v < e[nb];
+    if (inside && !(v >= e[k] && v < e[k + 1])) {  // arbitrary increasing tables: walk (never taken for uniform bins)
         while (k > 1 && v < e[k]) --k;
         while (k < nb - 1 && v >= e[k + 1]) ++k;
     }
-    return k;
+    k = v < e[1] ? 0 : k;
+    return (v >= e[nb] || !(v == v)) ? nb : k;
+}
+
+// Same result without touching memory, for tables that equal NumPy's float32 arange bit for bit:
+// edges[j] = fl32(first + fl32(fl32(j-1) * delta)) for j >= 1 (separately rounded multiply and add, which is what
+// -ffp-contract=off compiles to).  Whether a table has that form is checked once per workgroup (edges_are_arange).
+__device__ __forceinline__ float arange_edge(int j, float first, float delta) { return first + (float)(j - 1) * delta; }
+
+__device__ __forceinline__ int digitize_arange(float v, float first, float delta, float e_last, int nb, float inv_width) {
+    int k = 1 + (int)((v - first) * inv_width);
+    k = k < 1 ? 1 : (k > nb - 1 ? nb - 1 : k);
+    k += (v >= arange_edge(k + 1, first, delta)) - (v < arange_edge(k, first, delta));
+    k = k < 1 ? 1 : (k > nb - 1 ? nb - 1 : k);
+    const bool inside = v >= first && v < e_last;
+    if (inside && !(v >= arange_edge(k, first, delta) && v < arange_edge(k + 1, first, delta))) {
+        while (k > 1 && v < arange_edge(k, first, delta)) --k;
+        while (k < nb - 1 && v >= arange_edge(k + 1, first, delta)) ++k;
+    }
+    k = v < first ? 0 : k;
+    return (v >= e_last || !(v == v)) ? nb : k;
+}
+
+// block-wide: does the LDS copy e[0..nb] of the edge table have the arange form?  (all threads must call)
+__device__ __forceinline__ bool edges_are_arange(const float* e, int nb) {
+    const float first = e[1], delta = e[2] - e[1];
+    bool ok = delta > 0.f;
+    for (int j = 1 + (int)threadIdx.x; j <= nb; j += (int)blockDim.x)
+        ok = ok && (__float_as_uint(e[j]) == __float_as_uint(arange_edge(j, first, delta)));
+    return __syncthreads_and(ok ? 1 : 0) != 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -300,73 +327,80 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
     if (do_bins)
         for (int i = tid; i <= nb; i += 256) e[i] = edges[i];
     __syncthreads();
-    float inv_width = 0.f;
-    if (do_bins) inv_width = (float)(nb - 1) / (e[nb] - e[1]);
+    float inv_width = 0.f, e_first = 0.f, e_delta = 0.f, e_last = 0.f;
+    bool arange_tab = false;
+    if (do_bins) {
+        inv_width = (float)(nb - 1) / (e[nb] - e[1]);
+        e_first = e[1];
+        e_delta = e[2] - e[1];
+        e_last = e[nb];
+        arange_tab = edges_are_arange(e, nb) && !(ablate & 512);
+    }
 
     int n_invalid = 0;
     if (chunk == 0 && mask && active) mask[c] = finite_f(x[c]) ? 1 : 0;
     if (ablate & 256) return;  // timing only: launch + init
+    // Inactive lanes (beyond C) stream -- and store -- the last cell instead of being masked off: loads and
+    // stores stay unconditional and uniform in control flow (duplicate stores write identical values).
+    const unsigned cidx = active ? (unsigned)c : (unsigned)(C - 1);
 
     // One (dayofyear i, year y) element: climatology from the ring, anomaly, bin, then push s into the ring.
     // pl = {timestep, output row, bin-matrix row} (-1: none).  The ring is read with NO predicates: the slots
     // of years y-W .. y-1 in ascending order (slot0, slot0+1, ... mod W), then the +0.0 pad slots.
     auto emit = [&](int i, int slot0, const int4 pl, float xc, float s) {
         if (ablate & 1) {  // timing only: keep the inputs alive, skip climatology / anomaly / bins / stores
-            if (xc + s == 12345.678f && active) out[c] = xc;
+            if (xc + s == 12345.678f) out[cidx] = xc;
             return;
         }
         float* col = ring + (size_t)i * WCAP * 256 + tid;
-        if (pl.x >= 0) {
-            if (!finite_f(xc)) ++n_invalid;
-            if (pl.y >= 0) {
-                float clim = nan_f();
-                if (write_clim || xc == xc) {
-                    float rv[WCAP];
-                    float acc = 0.f;
-                    int n = W;
-                    if (ablate & 8) {
-                        acc = s;
-                    } else {
+        if (pl.x >= 0) {  // uniform
+            n_invalid += finite_f(xc) ? 0 : 1;
+            if (pl.y >= 0) {  // uniform: this timestep is an output row
+                float rv[WCAP];
+                float acc = 0.f;
+                int n = W;
+                if (ablate & 8) {
+                    acc = s;
+                } else {
 #pragma unroll
-                        for (int j = 0; j < WCAP; ++j) {
+                    for (int j = 0; j < WCAP; ++j) {
+                        int sl = slot0 + j;
+                        sl = sl >= W ? sl - W : sl;
+                        sl = j < W ? sl : j;
+                        rv[j] = col[sl * 256];
+                    }
+#pragma unroll
+                    for (int j = 0; j < WCAP; ++j) acc += rv[j];
+                    // a NaN term (leap day, first days of the series, gaps): redo as nanmean.  Land lanes (NaN
+                    // centre value) never need it -- their anomaly is NaN whatever the climatology is.
+                    if (!(acc == acc) && (write_clim || xc == xc)) {
+                        acc = 0.f;
+                        n = 0;
+                        for (int j = 0; j < W; ++j) {
                             int sl = slot0 + j;
                             sl = sl >= W ? sl - W : sl;
-                            sl = j < W ? sl : j;
-                            rv[j] = col[sl * 256];
-                        }
-#pragma unroll
-                        for (int j = 0; j < WCAP; ++j) acc += rv[j];
-                        if (!(acc == acc)) {  // a NaN term: redo as nanmean (rare: leap day, first days, gaps)
-                            acc = 0.f;
-                            n = 0;
-                            for (int j = 0; j < W; ++j) {
-                                int sl = slot0 + j;
-                                sl = sl >= W ? sl - W : sl;
-                                const float v = col[sl * 256];
-                                if (v == v) {
-                                    acc += v;
-                                    ++n;
-                                }
+                            const float v = col[sl * 256];
+                            if (v == v) {
+                                acc += v;
+                                ++n;
                             }
                         }
                     }
-                    clim = (ablate & 16) ? acc : acc / (float)n;  // n == 0 -> 0/0 = NaN
                 }
-                if (active) {
-                    const float a = xc - clim;
-                    if (!(ablate & 64)) out[(size_t)pl.y * C + c] = write_clim ? clim : a;
-                    if (do_bins && !(ablate & 32))
-                        bins[bins_index(pl.z, c, T_out)] = (unsigned short)digitize_bin(a, e, nb, inv_width);
-                    if ((ablate & 96) == 96 && a == 12345.678f) out[c] = a;
-                }
+                const float clim = (ablate & 16) ? acc : acc / (float)n;  // n == 0 -> 0/0 = NaN
+                const float a = xc - clim;
+                // lanes beyond C duplicate the last cell (same inputs, same values): stores need no guard
+                if (!(ablate & 64)) out[(size_t)pl.y * C + cidx] = write_clim ? clim : a;
+                if (do_bins && !(ablate & 32))
+                    bins[(ablate & 1024) ? (size_t)cidx : bins_index(pl.z, cidx, T_out)] = (unsigned short)(
+                        arange_tab ? digitize_arange(a, e_first, e_delta, e_last, nb, inv_width)
+                                   : digitize_bin(a, e, nb, inv_width));
+                if ((ablate & 96) == 96 && a == 12345.678f) out[cidx] = a;
             }
         }
         col[slot0 * 256] = (pl.x >= 0) ? s : nan_f();
     };
 
-    // Inactive lanes (beyond C) stream the last cell instead of being masked off: loads stay unconditional
-    // and uniform in control flow; only the stores are guarded by `active`.
-    const unsigned cidx = active ? (unsigned)c : (unsigned)(C - 1);
     constexpr int NL = D + SCAP - 1;
     float xw[NL];
     for (int y = 0; y < n_cal; ++y) {
