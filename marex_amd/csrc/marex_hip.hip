@@ -401,6 +401,74 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
         col[slot0 * 256] = (pl.x >= 0) ? s : nan_f();
     };
 
+    // The same for all D dayofyears of a year at once, phase by phase, so that the D independent dependency
+    // chains (ring sums, divisions, bin search) overlap instead of running one after the other.  Used when every
+    // one of the D timesteps is an output row (the common case after the first W years).
+    auto emit_all = [&](int slot0, const int4 (&pl)[D], const float (&xc)[D], const float (&sm)[D]) {
+        float rv[D][WCAP];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const float* col = ring + (size_t)i * WCAP * 256 + tid;
+#pragma unroll
+            for (int j = 0; j < WCAP; ++j) {
+                int sl = slot0 + j;
+                sl = sl >= W ? sl - W : sl;
+                sl = j < W ? sl : j;
+                rv[i][j] = col[sl * 256];
+            }
+        }
+        float acc[D];
+        int n[D];
+        bool slow = false;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            acc[i] = 0.f;
+            n[i] = W;
+            n_invalid += finite_f(xc[i]) ? 0 : 1;
+        }
+#pragma unroll
+        for (int j = 0; j < WCAP; ++j)
+#pragma unroll
+            for (int i = 0; i < D; ++i) acc[i] += rv[i][j];
+#pragma unroll
+        for (int i = 0; i < D; ++i) slow |= !(acc[i] == acc[i]) && (write_clim || xc[i] == xc[i]);
+        if (slow) {  // a NaN term somewhere (leap day, first days of the series, gaps): nanmean for those
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                if (!(acc[i] == acc[i]) && (write_clim || xc[i] == xc[i])) {
+                    acc[i] = 0.f;
+                    n[i] = 0;
+#pragma unroll
+                    for (int j = 0; j < WCAP; ++j) {
+                        if (j < W && rv[i][j] == rv[i][j]) {
+                            acc[i] += rv[i][j];
+                            ++n[i];
+                        }
+                    }
+                }
+            }
+        }
+        float a[D], clim[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            clim[i] = acc[i] / (float)n[i];  // n == 0 -> 0/0 = NaN
+            a[i] = xc[i] - clim[i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) out[(size_t)pl[i].y * C + cidx] = write_clim ? clim[i] : a[i];
+        if (do_bins) {
+            int kb[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+                kb[i] = arange_tab ? digitize_arange(a[i], e_first, e_delta, e_last, nb, inv_width)
+                                   : digitize_bin(a[i], e, nb, inv_width);
+#pragma unroll
+            for (int i = 0; i < D; ++i) bins[bins_index(pl[i].z, cidx, T_out)] = (unsigned short)kb[i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) ring[((size_t)i * WCAP + slot0) * 256 + tid] = sm[i];
+    };
+
     constexpr int NL = D + SCAP - 1;
     float xw[NL];
     for (int y = 0; y < n_cal; ++y) {
@@ -429,16 +497,30 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
                     rowp += C;
                 }
             }
+            float sacc[D], xcen[D], smo[D];
+            bool all_out = !ablate;
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                float acc = xw[i];
-                if (ablate & 2) {
-                    acc = xw[i] + xw[NL - 1];
-                } else {
+                sacc[i] = xw[i];
+                xcen[i] = xw[i + SCAP / 2];
+                all_out &= pl[i].y >= 0;
+            }
+            if (ablate & 2) {
 #pragma unroll
-                    for (int k = 1; k < SCAP; ++k) acc += xw[i + k];
-                }
-                emit(i, slot0, pl[i], xw[i + SCAP / 2], acc / Sf);
+                for (int i = 0; i < D; ++i) sacc[i] = xw[i] + xw[NL - 1];
+            } else {
+#pragma unroll
+                for (int k = 1; k < SCAP; ++k)
+#pragma unroll
+                    for (int i = 0; i < D; ++i) sacc[i] += xw[i + k];
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) smo[i] = sacc[i] / Sf;
+            if (all_out) {
+                emit_all(slot0, pl, xcen, smo);
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; ++i) emit(i, slot0, pl[i], xcen[i], smo[i]);
             }
         } else {
             // generic path: every present dayofyear loads its own S rows with range checks (series ends,
