@@ -294,15 +294,20 @@ extern "C" int marex_synth_sst_f32(marex_ctx* ctx, const float* mean, const floa
 // is read by ceil((D+S-1)/D) chunks; blocks of one cell block are placed on one XCD so that those
 // re-reads are L2 / Infinity-Cache hits and HBM sees every byte of x about once.
 // ------------------------------------------------------------------------------------------------
-template <int D, int SCAP, bool SEXACT, int WCAP>
+template <int D, int SCAP, bool SEXACT, int WCAP, bool RREG>
 __global__ void __launch_bounds__(256)
 k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__ year_plan, int n_cal, int W,
            int S_rt, int write_clim, const float* __restrict__ edges, int nb, long T_out, float* __restrict__ out,
            unsigned short* __restrict__ bins, unsigned char* __restrict__ mask, int* __restrict__ invalid_count,
            int ncb, int nchunks, int ablate) {
     extern __shared__ float lds[];
-    float* ring = lds;                        // [D][WCAP][256]; slots W..WCAP-1 hold +0.0 (neutral in the sum)
-    int4* lplan = reinterpret_cast<int4*>(lds + (size_t)D * WCAP * 256);  // [n_cal][D] this chunk's plan column
+    // W-year history of every (cell, dayofyear).  LDS ring [D][WCAP][256] (slots W..WCAP-1 hold +0.0, neutral in
+    // the sum), or -- RREG -- a register shift line per dayofyear: rr[i][WCAP-W .. WCAP-1] = years y-W .. y-1,
+    // the leading WCAP-W entries stay +0.0.  The register line frees the LDS, so occupancy is set by VGPRs only.
+    float* ring = lds;
+    float rr[RREG ? D : 1][RREG ? WCAP : 1];
+    const int npad = WCAP - W;
+    int4* lplan = reinterpret_cast<int4*>(lds + (RREG ? (size_t)0 : (size_t)D * WCAP * 256));  // [n_cal][D] plan column
     float* e = reinterpret_cast<float*>(lplan + (size_t)n_cal * D);      // [nb+1] when binning
 
     int cb, chunk;
@@ -316,8 +321,41 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
     const int d0 = chunk * D;
     const bool do_bins = bins != nullptr;
 
-    if (!(ablate & 128))
+    if (RREG) {
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < WCAP; ++j) rr[i][j] = j >= npad ? nan_f() : 0.f;
+    } else if (!(ablate & 128)) {
         for (int i = tid; i < D * WCAP * 256; i += 256) ring[i] = ((i >> 8) % WCAP) < W ? nan_f() : 0.f;
+    }
+    // ring_read: the W history values in ascending year order plus the +0.0 pads (LDS: pads last, RREG: pads first;
+    // adding +0.0 before or after changes nothing: the sum starts at +0.0).  ring_push: year y replaces year y-W.
+    auto ring_read = [&](int i, int slot0, float (&rv)[WCAP]) {
+        if (RREG) {
+#pragma unroll
+            for (int j = 0; j < WCAP; ++j) rv[j] = rr[i][j];
+        } else {
+            const float* col = ring + (size_t)i * WCAP * 256 + tid;
+#pragma unroll
+            for (int j = 0; j < WCAP; ++j) {
+                int sl = slot0 + j;
+                sl = sl >= W ? sl - W : sl;
+                sl = j < W ? sl : j;
+                rv[j] = col[sl * 256];
+            }
+        }
+    };
+    auto ring_push = [&](int i, int slot0, float v) {
+        if (RREG) {
+#pragma unroll
+            for (int j = 0; j < WCAP - 1; ++j) rr[i][j] = j >= npad ? rr[i][j + 1] : 0.f;
+            rr[i][WCAP - 1] = v;
+        } else {
+            ring[((size_t)i * WCAP + slot0) * 256 + tid] = v;
+        }
+    };
+    auto is_real = [&](int j) { return RREG ? j >= npad : j < W; };
     // the chunk's {timestep, output row, bin row} entries of every year, staged once: the year loop then reads
     // them from LDS instead of waiting on a scalar global load per year (dayofyears past 366 count as absent)
     for (int i = tid; i < n_cal * D; i += 256) {
@@ -352,7 +390,6 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
             if (xc + s == 12345.678f) out[cidx] = xc;
             return;
         }
-        float* col = ring + (size_t)i * WCAP * 256 + tid;
         if (pl.x >= 0) {  // uniform
             n_invalid += finite_f(xc) ? 0 : 1;
             if (pl.y >= 0) {  // uniform: this timestep is an output row
@@ -362,13 +399,7 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
                 if (ablate & 8) {
                     acc = s;
                 } else {
-#pragma unroll
-                    for (int j = 0; j < WCAP; ++j) {
-                        int sl = slot0 + j;
-                        sl = sl >= W ? sl - W : sl;
-                        sl = j < W ? sl : j;
-                        rv[j] = col[sl * 256];
-                    }
+                    ring_read(i, slot0, rv);
 #pragma unroll
                     for (int j = 0; j < WCAP; ++j) acc += rv[j];
                     // a NaN term (leap day, first days of the series, gaps): redo as nanmean.  Land lanes (NaN
@@ -376,12 +407,10 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
                     if (!(acc == acc) && (write_clim || xc == xc)) {
                         acc = 0.f;
                         n = 0;
-                        for (int j = 0; j < W; ++j) {
-                            int sl = slot0 + j;
-                            sl = sl >= W ? sl - W : sl;
-                            const float v = col[sl * 256];
-                            if (v == v) {
-                                acc += v;
+#pragma unroll
+                        for (int j = 0; j < WCAP; ++j) {
+                            if (is_real(j) && rv[j] == rv[j]) {
+                                acc += rv[j];
                                 ++n;
                             }
                         }
@@ -398,7 +427,7 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
                 if ((ablate & 96) == 96 && a == 12345.678f) out[cidx] = a;
             }
         }
-        col[slot0 * 256] = (pl.x >= 0) ? s : nan_f();
+        ring_push(i, slot0, (pl.x >= 0) ? s : nan_f());
     };
 
     // The same for all D dayofyears of a year at once, phase by phase, so that the D independent dependency
@@ -407,16 +436,7 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
     auto emit_all = [&](int slot0, const int4 (&pl)[D], const float (&xc)[D], const float (&sm)[D]) {
         float rv[D][WCAP];
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const float* col = ring + (size_t)i * WCAP * 256 + tid;
-#pragma unroll
-            for (int j = 0; j < WCAP; ++j) {
-                int sl = slot0 + j;
-                sl = sl >= W ? sl - W : sl;
-                sl = j < W ? sl : j;
-                rv[i][j] = col[sl * 256];
-            }
-        }
+        for (int i = 0; i < D; ++i) ring_read(i, slot0, rv[i]);
         float acc[D];
         int n[D];
         bool slow = false;
@@ -440,7 +460,7 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
                     n[i] = 0;
 #pragma unroll
                     for (int j = 0; j < WCAP; ++j) {
-                        if (j < W && rv[i][j] == rv[i][j]) {
+                        if (is_real(j) && rv[i][j] == rv[i][j]) {
                             acc[i] += rv[i][j];
                             ++n[i];
                         }
@@ -466,7 +486,7 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
             for (int i = 0; i < D; ++i) bins[bins_index(pl[i].z, cidx, T_out)] = (unsigned short)kb[i];
         }
 #pragma unroll
-        for (int i = 0; i < D; ++i) ring[((size_t)i * WCAP + slot0) * 256 + tid] = sm[i];
+        for (int i = 0; i < D; ++i) ring_push(i, slot0, sm[i]);
     };
 
     constexpr int NL = D + SCAP - 1;
@@ -481,7 +501,7 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
             any |= pl[i].x >= 0;
             fast &= (pl[i].x >= 0) && (pl[i].x == pl[0].x + i);
         }
-        if (!any && y < W) continue;  // nothing to read, and the ring slot of this year still holds its initial NaN
+        if (!RREG && !any && y < W) continue;  // nothing to read, and the ring slot of this year still holds its initial NaN
         const int slot0 = y % W;
         const long r0 = (long)pl[0].x - lo;
         if (fast && SEXACT && r0 >= 0 && r0 + NL <= T) {
@@ -561,13 +581,13 @@ struct ShiftArgs {
     int32_t* invalid_count;
 };
 
-template <int D, int SCAP, bool SEXACT, int WCAP>
+template <int D, int SCAP, bool SEXACT, int WCAP, bool RREG>
 static int launch_shifting(marex_ctx* ctx, const ShiftArgs& a) {
     const int ncb = (int)((a.C + 255) / 256);
     const int nchunks = (NDOY + D - 1) / D;
-    const size_t lds = ((size_t)D * WCAP * 256 + (a.bins ? (size_t)a.nb + 1 : 0)) * sizeof(float) + (size_t)a.n_cal * D * 16;
+    const size_t lds = ((RREG ? (size_t)0 : (size_t)D * WCAP * 256) + (a.bins ? (size_t)a.nb + 1 : 0)) * sizeof(float) + (size_t)a.n_cal * D * 16;
     if (lds > 80 * 1024) return fail(ctx, -4, "marex_shifting_baseline_f32: window_year_baseline=%d needs more than 80 KiB of LDS", a.W);
-    auto kern = k_shifting<D, SCAP, SEXACT, WCAP>;
+    auto kern = k_shifting<D, SCAP, SEXACT, WCAP, RREG>;
     if (lds > 48 * 1024)
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
@@ -580,10 +600,10 @@ static int launch_shifting(marex_ctx* ctx, const ShiftArgs& a) {
     return 0;
 }
 
-template <int D, int WCAP>
+template <int D, int WCAP, bool RREG>
 static int dispatch_shifting_S(marex_ctx* ctx, const ShiftArgs& a) {
-    if (a.S == 21) return launch_shifting<D, 21, true, WCAP>(ctx, a);
-    return launch_shifting<D, 1, false, WCAP>(ctx, a);  // any other smoothing width: generic row loop
+    if (a.S == 21) return launch_shifting<D, 21, true, WCAP, RREG>(ctx, a);
+    return launch_shifting<D, 1, false, WCAP, RREG>(ctx, a);  // any other smoothing width: generic row loop
 }
 
 extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
@@ -605,9 +625,16 @@ extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64
     // 4 dayofyears per workgroup (6 row loads per output) while the padded W-year LDS ring leaves room for two
     // workgroups per CU, otherwise one dayofyear
     const int forceD = env_int("MAREX_SHIFT_D", 0);
-    if (W <= 8) return forceD == 1 ? dispatch_shifting_S<1, 8>(ctx, a) : dispatch_shifting_S<4, 8>(ctx, a);
-    if (W <= 16) return forceD == 1 ? dispatch_shifting_S<1, 16>(ctx, a) : dispatch_shifting_S<4, 16>(ctx, a);
-    return dispatch_shifting_S<1, 64>(ctx, a);
+    const int reg = env_int("MAREX_SHIFT_RING", 1);  // 1 (default): history in registers, 0: LDS ring
+    if (W <= 8) {
+        if (reg) return forceD == 2 ? dispatch_shifting_S<2, 8, true>(ctx, a) : forceD == 8 ? dispatch_shifting_S<8, 8, true>(ctx, a) : dispatch_shifting_S<4, 8, true>(ctx, a);
+        return forceD == 1 ? dispatch_shifting_S<1, 8, false>(ctx, a) : dispatch_shifting_S<4, 8, false>(ctx, a);
+    }
+    if (W <= 16) {
+        if (reg) return forceD == 2 ? dispatch_shifting_S<2, 16, true>(ctx, a) : dispatch_shifting_S<4, 16, true>(ctx, a);
+        return forceD == 1 ? dispatch_shifting_S<1, 16, false>(ctx, a) : dispatch_shifting_S<4, 16, false>(ctx, a);
+    }
+    return dispatch_shifting_S<1, 64, false>(ctx, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1283,7 +1310,10 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
     const bool band_ok = (1 << shift) <= 64 && p <= 3 && max_bucket > 0 && (int64_t)max_bucket * wd * ws * ws <= 65535;
     if (algo != 1 && band_ok) {
         // tile: 16x16 cells / 256 threads, or 32x32 / 1024 threads (less halo redundancy, more output lanes)
-        const bool big = (ny > 0 && p > 0) && env_int("MAREX_THR_TILE", 16) == 32 && (row1 - row0) >= 16 && nx >= 16;
+        // long dayofyear buckets (many years) make the kernel sample-streaming bound: the big tile re-streams
+        // 1.31x instead of 1.78x halo cells per output cell (measured 17.4 vs 23.3 ms on an 85-year band)
+        const int tile_pref = env_int("MAREX_THR_TILE", max_bucket >= 24 ? 32 : 16);
+        const bool big = (ny > 0 && p > 0) && tile_pref == 32 && (row1 - row0) >= 16 && nx >= 16;
         const int NT = big ? 1024 : 256;
         const int TR = (ny > 0 && p > 0) ? (big ? 32 : 16) : 1, TC = NT / TR;
         const int OR = TR - 2 * p, OC = TC - 2 * p;

@@ -137,9 +137,20 @@ def test_threshold_edge_quantiles_and_windows(hot):
 
 
 def test_shifting_chunk_variants(hot, monkeypatch):
-    """Every dayofyear-chunk width of the anomaly kernel gives identical bits."""
-    for D in ("1", "4"):
+    """Every dayofyear-chunk width / history placement (registers or LDS ring) of the anomaly kernel gives
+    identical bits, for W inside both ring capacities (8 and 16)."""
+    for ring, D in (("0", "1"), ("0", "4"), ("1", "2"), ("1", "4"), ("1", "8")):
+        monkeypatch.setenv("MAREX_SHIFT_RING", ring)
         monkeypatch.setenv("MAREX_SHIFT_D", D)
         r = run_case(hot, "2003-01-01", 9 * 365 + 2, 7, 21, 4, 21, 11, 5)
         check_all(*r)
+        r = run_case(hot, "1990-06-01", 20 * 365 + 5, 5, 9, 13, 21, 11, 3)
+        check_all(*r)
     monkeypatch.delenv("MAREX_SHIFT_D")
+    monkeypatch.delenv("MAREX_SHIFT_RING")
+
+
+def test_long_buckets_pick_the_big_tile(hot):
+    """28 output years per dayofyear bucket on a 20x40 grid: the threshold entry point switches to 32x32 tiles."""
+    r = run_case(hot, "1985-01-01", 32 * 365 + 8, 20, 40, 4, 21, 11, 5)
+    check_all(*r)
