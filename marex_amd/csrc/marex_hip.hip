@@ -35,6 +35,7 @@ struct marex_ctx {
     std::vector<TimedLaunch> pending;
     double total_ms[MAREX_K_COUNT] = {0};
     int64_t launches[MAREX_K_COUNT] = {0};
+    int* shift_info = nullptr;  // device, SHIFT_INFO_WORDS ints: which dayofyear chunks the fast anomaly kernel takes
 };
 
 static int fail(marex_ctx* ctx, int code, const char* fmt, ...) {
@@ -106,6 +107,7 @@ extern "C" int marex_create(int device, marex_ctx** out) {
 extern "C" int marex_destroy(marex_ctx* ctx) {
     if (!ctx) return -1;
     drain_timers(ctx);
+    if (ctx->shift_info) (void)hipFree(ctx->shift_info);
     delete ctx;
     return 0;
 }
@@ -299,7 +301,7 @@ __global__ void __launch_bounds__(256)
 k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__ year_plan, int n_cal, int W,
            int S_rt, int write_clim, const float* __restrict__ edges, int nb, long T_out, float* __restrict__ out,
            unsigned short* __restrict__ bins, unsigned char* __restrict__ mask, int* __restrict__ invalid_count,
-           int ncb, int nchunks, int ablate) {
+           int ncb, int nchunks, int ablate, const int* __restrict__ skip) {
     extern __shared__ float lds[];
     // W-year history of every (cell, dayofyear).  LDS ring [D][WCAP][256] (slots W..WCAP-1 hold +0.0, neutral in
     // the sum), or -- RREG -- a register shift line per dayofyear: rr[i][WCAP-W .. WCAP-1] = years y-W .. y-1,
@@ -312,6 +314,7 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
 
     int cb, chunk;
     if (!xcd_swizzle(blockIdx.x, ncb, nchunks, cb, chunk)) return;
+    if (D == 4 && skip && skip[chunk]) return;  // this chunk of 4 dayofyears belongs to k_shift_fast
     const int tid = threadIdx.x;
     const long c = (long)cb * 256 + tid;
     const bool active = c < C;
@@ -566,6 +569,325 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
     if (invalid_count && active && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K_A fast path: the same arithmetic as k_shifting for the regular part of the calendar, written for
+// the VALU (which is what bounds k_shifting: 386 vector instructions per wave, year and 4 dayofyears).
+//
+//   * wave = 64 cells x 4 consecutive dayofyears; the 4 waves of a workgroup take 4 neighbouring
+//     chunks of the SAME 64 cells.  Everything about the calendar is wave-uniform and lives in SGPRs
+//     (the plan is read with scalar loads one year ahead), so row addresses are SGPR base + lane offset.
+//   * two dayofyears per instruction: packed float32 (v_pk_add/mul/fma_f32).  The two smoothing chains
+//     of a pair are skewed by one step so that both add the SAME row in one instruction (op_sel
+//     broadcast) -- 23 instructions for the 40 sequential adds of a pair, bit-identical to the
+//     sequential sums (the lagging chain starts from -0.0, the identity of IEEE addition).
+//   * "/ S" and "/ W" are a * fl(1/b) followed by one Markstein correction step (two fma) and
+//     v_div_fixup_f32 for zeros / infinities: bit-identical to IEEE division for every float32 a and
+//     every b in 1..64 (exhaustive check: oracle/proofs/div_by_const.c).
+//   * np.digitize on an arange table: one fused guess, two edges recomputed with the table's own
+//     arithmetic, +-1 correction (classify() proves the guess is within one bin before enabling this).
+//   * the W-year history is a register shift line of exactly W packed pairs (template parameter).
+// Chunks the calendar makes irregular (leap day, gaps, series starting mid-chunk) and every other
+// configuration (S != 21, W > 16, arbitrary edge tables) stay on k_shifting; k_shift_classify decides
+// per chunk on the device, both kernels skip the other's chunks.
+// ------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// acc.lo += src.lo, acc.hi += src.lo  /  acc.lo += src.hi, acc.hi += src.hi
+__device__ __forceinline__ v2f pk_add_bc_lo(v2f acc, v2f src) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(acc), "v"(src));
+    return r;
+}
+__device__ __forceinline__ v2f pk_add_bc_hi(v2f acc, v2f src) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(acc), "v"(src));
+    return r;
+}
+__device__ __forceinline__ v2f splat2(float v) { return (v2f){v, v}; }
+
+// a / b for a constant b (y = fl(1/b)): bit-identical to IEEE division (see header comment)
+__device__ __forceinline__ v2f div_const2(v2f a, float b, float y) {
+    const v2f q = a * splat2(y);
+    const v2f r = __builtin_elementwise_fma(-q, splat2(b), a);
+    const v2f q2 = __builtin_elementwise_fma(r, splat2(y), q);
+    return (v2f){__builtin_amdgcn_div_fixupf(q2.x, b, a.x), __builtin_amdgcn_div_fixupf(q2.y, b, a.y)};
+}
+
+// Buffer addressing: 128-bit descriptor in SGPRs (wave-uniform base), 32-bit lane byte offset in a VGPR, 32-bit
+// uniform byte offset in an SGPR -- no vector instruction is spent on addresses.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float ldb_f32(rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ void stb_f32(rsrc_t r, unsigned voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, soff, 0);
+}
+__device__ __forceinline__ void stb_u16(rsrc_t r, unsigned voff, int soff, int v) {
+    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, r, (int)voff, soff, 0);
+}
+
+#define SHIFT_INFO_WORDS 128  // [0..91] chunk handled by the fast kernel, [92] arange edges usable
+
+__global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, const float* __restrict__ edges, int nb,
+                                 int want_bins, int enable, int* __restrict__ info) {
+    __shared__ int s_edges_ok;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        int ok = 1;
+        if (want_bins) {
+            const float first = edges[1], delta = edges[2] - edges[1], last = edges[nb];
+            ok = delta > 0.f && nb < 32768;
+            for (int j = 1; ok && j <= nb; ++j)
+                ok = __float_as_uint(edges[j]) == __float_as_uint(arange_edge(j, first, delta));
+            // the fused guess must land within one bin of the truth: generous bound on its rounding error
+            const double m = fabs((double)first) > fabs((double)last) ? fabs((double)first) : fabs((double)last);
+            ok = ok && ((double)nb + 2.0 * m / (double)delta) * (1.0 / 1048576.0) < 0.25;
+        }
+        s_edges_ok = ok && enable;
+        info[92] = s_edges_ok;
+    }
+    __syncthreads();
+    if (t >= 92) return;
+    const int d0 = t * 4;
+    int ok = s_edges_ok && d0 + 3 < NDOY;
+    for (int y = 0; ok && y < n_cal; ++y) {
+        const int4* p = year_plan + (size_t)y * NDOY + d0;
+        const int4 e0 = p[0];
+        if (e0.x < 0) {
+            for (int i = 1; i < 4; ++i) ok = ok && p[i].x < 0;
+            continue;
+        }
+        for (int i = 1; i < 4; ++i) {
+            const int4 e = p[i];
+            ok = ok && e.x == e0.x + i;
+            if (e0.y >= 0)
+                ok = ok && e.y == e0.y + i && e.z >= 0;
+            else
+                ok = ok && e.y < 0;
+        }
+        if (e0.y >= 0) ok = ok && e0.z >= 0;
+    }
+    info[t] = ok;
+}
+
+template <int W>
+__global__ void __launch_bounds__(256)
+k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict__ year_plan, int n_cal,
+             const int* __restrict__ info, int write_clim, const float* __restrict__ edges, int nb, long T_out, float* __restrict__ out, unsigned short* __restrict__ bins, unsigned char* __restrict__ mask,
+             int* __restrict__ invalid_count, int ncg, int nblk) {
+    int cg, bc;
+    if (!xcd_swizzle(blockIdx.x, ncg, nblk, cg, bc)) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int chunk = bc * 4 + wave;
+    // The 4 waves work on 4 neighbouring chunks of the same 64 cells: the 36 rows one calendar year needs for
+    // all 16 dayofyears are staged once in LDS (double buffered, loaded one year ahead) and every wave reads its
+    // 24 from there -- 2.25 instead of 6 row reads per output row leave the L2.
+    __shared__ float stage[2][36 * 64];
+    const bool mine = chunk < 92 && info[chunk] != 0;  // wave-uniform; the other waves only help staging
+    const int d0 = mine ? chunk * 4 : 0;
+    const int4* pblk = year_plan + bc * 16;  // first dayofyear of the workgroup (bc <= 22: always < 366)
+    const long c = (long)cg * 64 + lane;
+    const bool active = c < C;
+    const unsigned cidx = active ? (unsigned)c : (unsigned)(C - 1);  // lanes beyond C duplicate the last cell
+    const bool do_bins = bins != nullptr;
+    // bin matrix: lane part of the element index relative to the wave's first 16-cell block
+    const unsigned voff = cidx * 4u;  // byte offset of the lane's cell inside a (time, cell) row
+    const int rowb = (int)(C * 4);    // bytes per (time, cell) row
+    const unsigned bin_lane = (((cidx >> 4) - (unsigned)(cg * 4)) * (unsigned)T_out * 16u + (cidx & 15u)) * 2u;  // bytes
+    const rsrc_t rbins = make_rsrc(do_bins ? bins + (size_t)(cg * 4) * (size_t)T_out * 16 : nullptr);
+
+    float e_first = 0.f, e_delta = 1.f, inv_width = 1.f;
+    if (do_bins) {
+        e_first = edges[1];
+        e_delta = edges[2] - edges[1];
+        inv_width = (float)(nb - 1) / (edges[nb] - e_first);
+    }
+    constexpr float Sf = 21.f;
+    const float yS = 1.0f / Sf;
+    const float Wf = (float)W;
+    const float yW = 1.0f / Wf;
+    const float nbm1f = (float)(nb - 1);
+    const float c0 = 1.0f - e_first * inv_width;
+    const float qnan = nan_f();
+
+    if (chunk == 0 && mine && mask && active) mask[c] = finite_f(x[c]) ? 1 : 0;
+    // rows tb-10 .. tb+25 (tb = timestep of the workgroup's first dayofyear in that year) can be staged when they
+    // all lie inside the series; this wave loads rows 9*wave .. 9*wave+8 of them
+    auto stage_ok = [&](int tb) { return tb >= 10 && (long)tb + 26 <= T; };
+    auto stage_load = [&](int tb, float (&nx)[9]) {
+        const rsrc_t rs = make_rsrc(x + (size_t)(tb - 10 + 9 * wave) * C);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) nx[k] = ldb_f32(rs, voff, k * rowb);
+    };
+    auto stage_store = [&](int buf, const float (&nx)[9]) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) stage[buf][(9 * wave + k) * 64 + lane] = nx[k];
+    };
+    int tb_next = pblk[0].x;
+    {
+        float nx[9];
+        if (stage_ok(tb_next)) {
+            stage_load(tb_next, nx);
+            stage_store(0, nx);
+        }
+    }
+    __syncthreads();
+
+    v2f rA[W], rB[W];  // history of dayofyears (0,1) and (2,3): [0] = year y-W ... [W-1] = year y-1
+#pragma unroll
+    for (int j = 0; j < W; ++j) rA[j] = rB[j] = splat2(qnan);
+    int n_invalid = 0;
+
+    const int4* pp = year_plan + d0;
+    int4 n0 = pp[0], n1 = pp[1], n2 = pp[2], n3 = pp[3];
+    for (int y = 0; y < n_cal; ++y) {
+        const int4 p0 = n0, p1 = n1, p2 = n2, p3 = n3;
+        const int tb = tb_next;
+        float nx[9];
+        bool stage_next = false;
+        if (y + 1 < n_cal) {  // next year's plan and rows, one iteration ahead
+            const int4* q = pp + (size_t)(y + 1) * NDOY;
+            n0 = q[0];
+            n1 = q[1];
+            n2 = q[2];
+            n3 = q[3];
+            tb_next = pblk[(size_t)(y + 1) * NDOY].x;
+            stage_next = stage_ok(tb_next);
+            if (stage_next) stage_load(tb_next, nx);
+        }
+        v2f smA = splat2(qnan), smB = splat2(qnan);
+        if (mine && p0.x >= 0) {
+            const long r0 = (long)p0.x - 10;
+            v2f xp[12];  // xp[m] = rows (r0 + 2m, r0 + 2m + 1)
+            const bool edge = r0 < 0 || r0 + 24 > T;
+            if (stage_ok(tb) && p0.x == tb + 4 * wave) {
+                const float* st = &stage[y & 1][(4 * wave) * 64 + lane];
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    xp[m].x = st[(2 * m) * 64];
+                    xp[m].y = st[(2 * m + 1) * 64];
+                }
+            } else if (!edge) {
+                const rsrc_t rx = make_rsrc(x + (size_t)r0 * C);
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    xp[m].x = ldb_f32(rx, voff, (2 * m) * rowb);
+                    xp[m].y = ldb_f32(rx, voff, (2 * m + 1) * rowb);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    long ra = r0 + 2 * m, rb = ra + 1;
+                    ra = ra < 0 ? 0 : (ra > T - 1 ? T - 1 : ra);
+                    rb = rb < 0 ? 0 : (rb > T - 1 ? T - 1 : rb);
+                    xp[m].x = ldb_f32(make_rsrc(x + (size_t)ra * C), voff, 0);
+                    xp[m].y = ldb_f32(make_rsrc(x + (size_t)rb * C), voff, 0);
+                }
+            }
+            // smoothing: sequential sums of rows i .. i+20 for the four dayofyears i = 0..3
+            v2f accA = (v2f){xp[0].x, -0.0f};
+#pragma unroll
+            for (int s = 1; s <= 20; ++s) accA = (s & 1) ? pk_add_bc_hi(accA, xp[s >> 1]) : pk_add_bc_lo(accA, xp[s >> 1]);
+            accA.y += xp[10].y;
+            v2f accB = (v2f){xp[1].x, -0.0f};
+#pragma unroll
+            for (int s = 3; s <= 22; ++s) accB = (s & 1) ? pk_add_bc_hi(accB, xp[s >> 1]) : pk_add_bc_lo(accB, xp[s >> 1]);
+            accB.y += xp[11].y;
+            smA = div_const2(accA, Sf, yS);
+            smB = div_const2(accB, Sf, yS);
+            if (edge) {  // windows that leave the series: NaN (a NaN row in the sum, in the general kernel)
+                const long t0 = p0.x;
+                smA.x = (t0 - 10 >= 0 && t0 + 10 < T) ? smA.x : qnan;
+                smA.y = (t0 - 9 >= 0 && t0 + 11 < T) ? smA.y : qnan;
+                smB.x = (t0 - 8 >= 0 && t0 + 12 < T) ? smB.x : qnan;
+                smB.y = (t0 - 7 >= 0 && t0 + 13 < T) ? smB.y : qnan;
+            }
+            const v2f xcA = xp[5], xcB = xp[6];
+            n_invalid += (finite_f(xcA.x) ? 0 : 1) + (finite_f(xcA.y) ? 0 : 1) + (finite_f(xcB.x) ? 0 : 1) +
+                         (finite_f(xcB.y) ? 0 : 1);
+            if (p0.y >= 0) {  // output rows
+                v2f sA = splat2(0.f), sB = splat2(0.f);
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    sA = sA + rA[j];
+                    sB = sB + rB[j];
+                }
+                v2f climA = div_const2(sA, Wf, yW), climB = div_const2(sB, Wf, yW);
+                // a NaN in the history (first days of the series, gaps) while the centre value is a number: nanmean
+                const bool slow = (!(climA.x == climA.x) && (write_clim || xcA.x == xcA.x)) ||
+                                  (!(climA.y == climA.y) && (write_clim || xcA.y == xcA.y)) ||
+                                  (!(climB.x == climB.x) && (write_clim || xcB.x == xcB.x)) ||
+                                  (!(climB.y == climB.y) && (write_clim || xcB.y == xcB.y));
+                if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                    int n[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int j = 0; j < W; ++j) {
+                        const float v[4] = {rA[j].x, rA[j].y, rB[j].x, rB[j].y};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (v[i] == v[i]) {
+                                acc[i] += v[i];
+                                ++n[i];
+                            }
+                    }
+                    // elements without a NaN term keep the fast result (identical: same sum, n == W)
+                    if (!(climA.x == climA.x)) climA.x = acc[0] / (float)n[0];
+                    if (!(climA.y == climA.y)) climA.y = acc[1] / (float)n[1];
+                    if (!(climB.x == climB.x)) climB.x = acc[2] / (float)n[2];
+                    if (!(climB.y == climB.y)) climB.y = acc[3] / (float)n[3];
+                }
+                const v2f aA = xcA - climA, aB = xcB - climB;
+                const rsrc_t ro = make_rsrc(out + (size_t)p0.y * C);
+                stb_f32(ro, voff, 0, write_clim ? climA.x : aA.x);
+                stb_f32(ro, voff, rowb, write_clim ? climA.y : aA.y);
+                stb_f32(ro, voff, 2 * rowb, write_clim ? climB.x : aB.x);
+                stb_f32(ro, voff, 3 * rowb, write_clim ? climB.y : aB.y);
+                if (do_bins) {
+                    // np.digitize(a, edges) - 1 on the arange table (contract C4)
+                    auto digit2 = [&](v2f a, int& k0, int& k1) {
+                        const v2f f = __builtin_elementwise_fma(a, splat2(inv_width), splat2(c0));
+                        v2f t;
+                        t.x = __builtin_amdgcn_fmed3f(__builtin_truncf(f.x), 1.0f, nbm1f);
+                        t.y = __builtin_amdgcn_fmed3f(__builtin_truncf(f.y), 1.0f, nbm1f);
+                        const v2f tm1 = t - splat2(1.0f);
+                        const v2f plo = tm1 * splat2(e_delta);
+                        const v2f phi = t * splat2(e_delta);
+                        const v2f elo = splat2(e_first) + plo;
+                        const v2f ehi = splat2(e_first) + phi;
+                        k0 = (int)t.x + (a.x >= ehi.x ? 1 : 0) - (a.x < elo.x ? 1 : 0);
+                        k1 = (int)t.y + (a.y >= ehi.y ? 1 : 0) - (a.y < elo.y ? 1 : 0);
+                        k0 = (a.x == a.x) ? k0 : nb;
+                        k1 = (a.y == a.y) ? k1 : nb;
+                    };
+                    int k0, k1, k2, k3;
+                    digit2(aA, k0, k1);
+                    digit2(aB, k2, k3);
+                    stb_u16(rbins, bin_lane, p0.z * 32, k0);
+                    stb_u16(rbins, bin_lane, p1.z * 32, k1);
+                    stb_u16(rbins, bin_lane, p2.z * 32, k2);
+                    stb_u16(rbins, bin_lane, p3.z * 32, k3);
+                }
+            }
+        }
+        // year y replaces year y-W
+#pragma unroll
+        for (int j = 0; j + 1 < W; ++j) {
+            rA[j] = rA[j + 1];
+            rB[j] = rB[j + 1];
+        }
+        rA[W - 1] = smA;
+        rB[W - 1] = smB;
+        if (stage_next) stage_store((y + 1) & 1, nx);
+        __syncthreads();
+    }
+    if (invalid_count && active && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
+}
+
 struct ShiftArgs {
     const float* x;
     int64_t T, C;
@@ -579,6 +901,7 @@ struct ShiftArgs {
     uint16_t* bins;
     uint8_t* mask;
     int32_t* invalid_count;
+    const int* skip;
 };
 
 template <int D, int SCAP, bool SEXACT, int WCAP, bool RREG>
@@ -590,14 +913,19 @@ static int launch_shifting(marex_ctx* ctx, const ShiftArgs& a) {
     auto kern = k_shifting<D, SCAP, SEXACT, WCAP, RREG>;
     if (lds > 48 * 1024)
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    {
-        LaunchTimer lt(ctx, MAREX_K_SHIFTING);
-        hipLaunchKernelGGL(kern, dim3(xcd_grid(ncb, nchunks)), dim3(256), lds, ctx->stream, a.x, (long)a.T, (long)a.C,
-                           a.year_plan, a.n_cal, a.W, a.S, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins,
-                           a.mask, a.invalid_count, ncb, nchunks, env_int("MAREX_SHIFT_ABLATE", 0));
-    }
+    hipLaunchKernelGGL(kern, dim3(xcd_grid(ncb, nchunks)), dim3(256), lds, ctx->stream, a.x, (long)a.T, (long)a.C,
+                       a.year_plan, a.n_cal, a.W, a.S, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins,
+                       a.mask, a.invalid_count, ncb, nchunks, env_int("MAREX_SHIFT_ABLATE", 0), D == 4 ? a.skip : nullptr);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
+}
+
+template <int W>
+static void launch_shift_fast(marex_ctx* ctx, const ShiftArgs& a) {
+    const int ncg = (int)((a.C + 63) / 64);
+    hipLaunchKernelGGL(k_shift_fast<W>, dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C,
+                       a.year_plan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask,
+                       a.invalid_count, ncg, 23);
 }
 
 template <int D, int WCAP, bool RREG>
@@ -620,12 +948,34 @@ extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64
     if (bins && (!edges || nb < 4 || nb > 65534 || T_out <= 0))
         return fail(ctx, -1, "marex_shifting_baseline_f32: binning needs edges, T_out and 4 <= nb <= 65534");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const ShiftArgs a{x, T, C, reinterpret_cast<const int4*>(year_plan), n_cal_years, W, S, write_clim,
-                      edges, nb, T_out, out, bins, mask, invalid_count};
+    ShiftArgs a{x, T, C, reinterpret_cast<const int4*>(year_plan), n_cal_years, W, S, write_clim,
+                edges, nb, T_out, out, bins, mask, invalid_count, nullptr};
     // 4 dayofyears per workgroup (6 row loads per output) while the padded W-year LDS ring leaves room for two
     // workgroups per CU, otherwise one dayofyear
     const int forceD = env_int("MAREX_SHIFT_D", 0);
     const int reg = env_int("MAREX_SHIFT_RING", 1);  // 1 (default): history in registers, 0: LDS ring
+    // regular chunks of the calendar go to k_shift_fast (S = 21, instantiated W, arange edge table)
+    const bool fast_w = W == 3 || W == 4 || W == 5 || W == 6 || W == 7 || W == 10 || W == 13 || W == 15;
+    const bool fast_cfg = env_int("MAREX_SHIFT_FAST", 1) != 0 && S == 21 && fast_w && forceD == 0 && T >= 24 &&
+                          T_out < (1 << 24) && C < (1 << 24) && env_int("MAREX_SHIFT_ABLATE", 0) == 0;
+    if (fast_cfg && !ctx->shift_info) HIP_TRY(ctx, hipMalloc((void**)&ctx->shift_info, SHIFT_INFO_WORDS * sizeof(int)));
+    LaunchTimer lt(ctx, MAREX_K_SHIFTING);  // one timed region: classify + fast kernel + general kernel
+    if (fast_cfg) {
+        hipLaunchKernelGGL(k_shift_classify, dim3(1), dim3(128), 0, ctx->stream, a.year_plan, n_cal_years, edges, nb,
+                           bins ? 1 : 0, 1, ctx->shift_info);
+        a.skip = ctx->shift_info;
+        switch (W) {
+            case 3: launch_shift_fast<3>(ctx, a); break;
+            case 4: launch_shift_fast<4>(ctx, a); break;
+            case 5: launch_shift_fast<5>(ctx, a); break;
+            case 6: launch_shift_fast<6>(ctx, a); break;
+            case 7: launch_shift_fast<7>(ctx, a); break;
+            case 10: launch_shift_fast<10>(ctx, a); break;
+            case 13: launch_shift_fast<13>(ctx, a); break;
+            default: launch_shift_fast<15>(ctx, a); break;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+    }
     if (W <= 8) {
         if (reg) return forceD == 2 ? dispatch_shifting_S<2, 8, true>(ctx, a) : forceD == 8 ? dispatch_shifting_S<8, 8, true>(ctx, a) : dispatch_shifting_S<4, 8, true>(ctx, a);
         return forceD == 1 ? dispatch_shifting_S<1, 8, false>(ctx, a) : dispatch_shifting_S<4, 8, false>(ctx, a);
