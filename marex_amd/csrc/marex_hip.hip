@@ -581,8 +581,9 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
 //     broadcast) -- 23 instructions for the 40 sequential adds of a pair, bit-identical to the
 //     sequential sums (the lagging chain starts from -0.0, the identity of IEEE addition).
 //   * "/ S" and "/ W" are a * fl(1/b) followed by one Markstein correction step (two fma) and
-//     v_div_fixup_f32 for zeros / infinities: bit-identical to IEEE division for every float32 a and
-//     every b in 1..64 (exhaustive check: oracle/proofs/div_by_const.c).
+//     v_div_fixup_f32 for zeros / infinities: bit-identical to IEEE division for every float32 a when b
+//     is odd or a power of two (exhaustive check over b <= 64: oracle/proofs/div_by_const.c; even b
+//     have ties among subnormal quotients and keep the real division).
 //   * np.digitize on an arange table: one fused guess, two edges recomputed with the table's own
 //     arithmetic, +-1 correction (classify() proves the guess is within one bin before enabling this).
 //   * the W-year history is a register shift line of exactly W packed pairs (template parameter).
@@ -605,7 +606,8 @@ __device__ __forceinline__ v2f pk_add_bc_hi(v2f acc, v2f src) {
 }
 __device__ __forceinline__ v2f splat2(float v) { return (v2f){v, v}; }
 
-// a / b for a constant b (y = fl(1/b)): bit-identical to IEEE division (see header comment)
+// a / b for a constant b (y = fl(1/b)): bit-identical to IEEE division for odd b and powers of two up to 64
+// (exhaustive over all 2^32 a: oracle/proofs/div_by_const.c; v_div_fixup supplies the +-0 and +-inf cases)
 __device__ __forceinline__ v2f div_const2(v2f a, float b, float y) {
     const v2f q = a * splat2(y);
     const v2f r = __builtin_elementwise_fma(-q, splat2(b), a);
@@ -642,9 +644,10 @@ __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, 
             ok = delta > 0.f && nb < 32768;
             for (int j = 1; ok && j <= nb; ++j)
                 ok = __float_as_uint(edges[j]) == __float_as_uint(arange_edge(j, first, delta));
-            // the fused guess must land within one bin of the truth: generous bound on its rounding error
+            // the fused guess (biased down by 1/128 bin) must land in the true bin or the one below: generous bound
+            // on its rounding error (about 8x what the individual roundings add up to)
             const double m = fabs((double)first) > fabs((double)last) ? fabs((double)first) : fabs((double)last);
-            ok = ok && ((double)nb + 2.0 * m / (double)delta) * (1.0 / 1048576.0) < 0.25;
+            ok = ok && ((double)nb + 2.0 * m / (double)delta) * (1.0 / 1048576.0) < 1.0 / 256.0;
         }
         s_edges_ok = ok && enable;
         info[92] = s_edges_ok;
@@ -652,23 +655,24 @@ __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, 
     __syncthreads();
     if (t >= 92) return;
     const int d0 = t * 4;
-    int ok = s_edges_ok && d0 + 3 < NDOY;
+    int ok = s_edges_ok;
+    // every year: the first m (0..4) dayofyears of the chunk present on consecutive timesteps, the rest absent
+    // (leap day; dayofyears past 366 in the last chunk); output rows all or none, consecutive
     for (int y = 0; ok && y < n_cal; ++y) {
-        const int4* p = year_plan + (size_t)y * NDOY + d0;
-        const int4 e0 = p[0];
-        if (e0.x < 0) {
-            for (int i = 1; i < 4; ++i) ok = ok && p[i].x < 0;
-            continue;
-        }
-        for (int i = 1; i < 4; ++i) {
-            const int4 e = p[i];
-            ok = ok && e.x == e0.x + i;
-            if (e0.y >= 0)
-                ok = ok && e.y == e0.y + i && e.z >= 0;
+        int4 e[4];
+        for (int i = 0; i < 4; ++i)
+            e[i] = (d0 + i < NDOY) ? year_plan[(size_t)y * NDOY + d0 + i] : make_int4(-1, -1, -1, 0);
+        int m = 0;
+        while (m < 4 && e[m].x >= 0) ++m;
+        for (int i = m; i < 4; ++i) ok = ok && e[i].x < 0;
+        for (int i = 1; i < m; ++i) {
+            ok = ok && e[i].x == e[0].x + i;
+            if (e[0].y >= 0)
+                ok = ok && e[i].y == e[0].y + i && e[i].z >= 0;
             else
-                ok = ok && e.y < 0;
+                ok = ok && e[i].y < 0;
         }
-        if (e0.y >= 0) ok = ok && e0.z >= 0;
+        if (m > 0 && e[0].y >= 0) ok = ok && e[0].z >= 0;
     }
     info[t] = ok;
 }
@@ -711,7 +715,7 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     const float Wf = (float)W;
     const float yW = 1.0f / Wf;
     const float nbm1f = (float)(nb - 1);
-    const float c0 = 1.0f - e_first * inv_width;
+    const float c0 = (1.0f - e_first * inv_width) - 0.0078125f;  // +1 (edges[0] = -inf) and the 1/128-bin downward bias
     const float qnan = nan_f();
 
     if (chunk == 0 && mine && mask && active) mask[c] = finite_f(x[c]) ? 1 : 0;
@@ -743,7 +747,9 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     int n_invalid = 0;
 
     const int4* pp = year_plan + d0;
-    int4 n0 = pp[0], n1 = pp[1], n2 = pp[2], n3 = pp[3];
+    const bool tail = d0 + 3 >= NDOY;  // last chunk: dayofyears 365, 366 and two that do not exist
+    const int4 absent = make_int4(-1, -1, -1, 0);
+    int4 n0 = pp[0], n1 = pp[1], n2 = tail ? absent : pp[2], n3 = tail ? absent : pp[3];
     for (int y = 0; y < n_cal; ++y) {
         const int4 p0 = n0, p1 = n1, p2 = n2, p3 = n3;
         const int tb = tb_next;
@@ -753,8 +759,8 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
             const int4* q = pp + (size_t)(y + 1) * NDOY;
             n0 = q[0];
             n1 = q[1];
-            n2 = q[2];
-            n3 = q[3];
+            n2 = tail ? absent : q[2];
+            n3 = tail ? absent : q[3];
             tb_next = pblk[(size_t)(y + 1) * NDOY].x;
             stage_next = stage_ok(tb_next);
             if (stage_next) stage_load(tb_next, nx);
@@ -807,8 +813,16 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                 smB.y = (t0 - 7 >= 0 && t0 + 13 < T) ? smB.y : qnan;
             }
             const v2f xcA = xp[5], xcB = xp[6];
-            n_invalid += (finite_f(xcA.x) ? 0 : 1) + (finite_f(xcA.y) ? 0 : 1) + (finite_f(xcB.x) ? 0 : 1) +
-                         (finite_f(xcB.y) ? 0 : 1);
+            const bool partial = p3.x < 0;  // only a prefix of the 4 dayofyears exists this year (leap day chunk)
+            if (!partial) {
+                n_invalid += (finite_f(xcA.x) ? 0 : 1) + (finite_f(xcA.y) ? 0 : 1) + (finite_f(xcB.x) ? 0 : 1) +
+                             (finite_f(xcB.y) ? 0 : 1);
+            } else {
+                n_invalid += finite_f(xcA.x) ? 0 : 1;
+                if (p1.x >= 0) n_invalid += finite_f(xcA.y) ? 0 : 1; else smA.y = qnan;
+                if (p2.x >= 0) n_invalid += finite_f(xcB.x) ? 0 : 1; else smB.x = qnan;
+                smB.y = qnan;
+            }
             if (p0.y >= 0) {  // output rows
                 v2f sA = splat2(0.f), sB = splat2(0.f);
 #pragma unroll
@@ -816,7 +830,17 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                     sA = sA + rA[j];
                     sB = sB + rB[j];
                 }
-                v2f climA = div_const2(sA, Wf, yW), climB = div_const2(sB, Wf, yW);
+                // the reciprocal form is exact for odd W and powers of two only (even W have halfway cases among
+                // subnormal quotients that it misrounds: oracle/proofs/div_by_const.c); other W divide for real
+                constexpr bool recip_exact = (W & 1) || (W & (W - 1)) == 0;
+                v2f climA, climB;
+                if (recip_exact) {
+                    climA = div_const2(sA, Wf, yW);
+                    climB = div_const2(sB, Wf, yW);
+                } else {
+                    climA = (v2f){sA.x / Wf, sA.y / Wf};
+                    climB = (v2f){sB.x / Wf, sB.y / Wf};
+                }
                 // a NaN in the history (first days of the series, gaps) while the centre value is a number: nanmean
                 const bool slow = (!(climA.x == climA.x) && (write_clim || xcA.x == xcA.x)) ||
                                   (!(climA.y == climA.y) && (write_clim || xcA.y == xcA.y)) ||
@@ -844,23 +868,23 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                 const v2f aA = xcA - climA, aB = xcB - climB;
                 const rsrc_t ro = make_rsrc(out + (size_t)p0.y * C);
                 stb_f32(ro, voff, 0, write_clim ? climA.x : aA.x);
-                stb_f32(ro, voff, rowb, write_clim ? climA.y : aA.y);
-                stb_f32(ro, voff, 2 * rowb, write_clim ? climB.x : aB.x);
-                stb_f32(ro, voff, 3 * rowb, write_clim ? climB.y : aB.y);
+                if (p1.x >= 0) stb_f32(ro, voff, rowb, write_clim ? climA.y : aA.y);
+                if (p2.x >= 0) stb_f32(ro, voff, 2 * rowb, write_clim ? climB.x : aB.x);
+                if (p3.x >= 0) stb_f32(ro, voff, 3 * rowb, write_clim ? climB.y : aB.y);
                 if (do_bins) {
-                    // np.digitize(a, edges) - 1 on the arange table (contract C4)
+                    // np.digitize(a, edges) - 1 on the arange table (contract C4): the guess, biased down, is the
+                    // true bin or the one below (k_shift_classify checked the error bound); one comparison with
+                    // the edge above it -- recomputed with the table's own arithmetic -- settles which.  A NaN
+                    // guess clamps to 0 and is replaced by nb at the end.
                     auto digit2 = [&](v2f a, int& k0, int& k1) {
                         const v2f f = __builtin_elementwise_fma(a, splat2(inv_width), splat2(c0));
                         v2f t;
-                        t.x = __builtin_amdgcn_fmed3f(__builtin_truncf(f.x), 1.0f, nbm1f);
-                        t.y = __builtin_amdgcn_fmed3f(__builtin_truncf(f.y), 1.0f, nbm1f);
-                        const v2f tm1 = t - splat2(1.0f);
-                        const v2f plo = tm1 * splat2(e_delta);
+                        t.x = __builtin_amdgcn_fmed3f(__builtin_floorf(f.x), 0.0f, nbm1f);
+                        t.y = __builtin_amdgcn_fmed3f(__builtin_floorf(f.y), 0.0f, nbm1f);
                         const v2f phi = t * splat2(e_delta);
-                        const v2f elo = splat2(e_first) + plo;
-                        const v2f ehi = splat2(e_first) + phi;
-                        k0 = (int)t.x + (a.x >= ehi.x ? 1 : 0) - (a.x < elo.x ? 1 : 0);
-                        k1 = (int)t.y + (a.y >= ehi.y ? 1 : 0) - (a.y < elo.y ? 1 : 0);
+                        const v2f ehi = splat2(e_first) + phi;  // edges[t + 1]
+                        k0 = (int)t.x + (a.x >= ehi.x ? 1 : 0);
+                        k1 = (int)t.y + (a.y >= ehi.y ? 1 : 0);
                         k0 = (a.x == a.x) ? k0 : nb;
                         k1 = (a.y == a.y) ? k1 : nb;
                     };
@@ -868,9 +892,9 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                     digit2(aA, k0, k1);
                     digit2(aB, k2, k3);
                     stb_u16(rbins, bin_lane, p0.z * 32, k0);
-                    stb_u16(rbins, bin_lane, p1.z * 32, k1);
-                    stb_u16(rbins, bin_lane, p2.z * 32, k2);
-                    stb_u16(rbins, bin_lane, p3.z * 32, k3);
+                    if (p1.x >= 0) stb_u16(rbins, bin_lane, p1.z * 32, k1);
+                    if (p2.x >= 0) stb_u16(rbins, bin_lane, p2.z * 32, k2);
+                    if (p3.x >= 0) stb_u16(rbins, bin_lane, p3.z * 32, k3);
                 }
             }
         }
