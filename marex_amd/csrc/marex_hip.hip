@@ -1309,15 +1309,14 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         s_unres = env_exact;
     }
 
-    // level mapping of the current pass
+    // level mapping of the current pass: level(b) = clamp((b >> lsh) + loff, 0, lhi)
+    //   coarse: lsh = shift, loff = 0, lhi = ngroups - 1;  fine band B0..B0+BW-1: lsh = 0, loff = 1 - B0, lhi = BW + 1
     bool fine = false;
     int B0 = 0, BW = 0, nlev = ngroups;
-    auto lvl = [&](int b) {
-        if (!fine) return b >> shift;
-        const int k = b - B0;
-        return k < 0 ? 0 : (k >= BW ? BW + 1 : k + 1);
-    };
+    int lsh = shift, loff = 0, lhi = ngroups - 1;
     const unsigned short* colbase = bins + bins_index(0, cell_valid ? cell : 0, T_out);  // rows are 16 elements apart
+    // Lanes outside the grid stream cell 0 (valid memory, uniform control flow) but add zeros.
+    const unsigned one_lo = cell_valid ? 1u : 0u, one_hi = cell_valid ? 0x10000u : 0u;
     // first TB_PRE samples of a dayofyear bucket of this lane's cell, kept in registers
     struct Pre {
         int b[TB_PRE];
@@ -1326,24 +1325,34 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
     auto load_bucket = [&](int d0) {
         Pre pr;
         pr.r0 = doy_start[d0];
-        pr.nd = cell_valid ? doy_start[d0 + 1] - pr.r0 : 0;  // lanes outside the grid never touch memory
+        pr.nd = doy_start[d0 + 1] - pr.r0;  // uniform
         const unsigned short* col = colbase + (size_t)pr.r0 * 16;
 #pragma unroll
         for (int u = 0; u < TB_PRE; ++u) pr.b[u] = (u < pr.nd) ? (int)col[(size_t)u * 16] : nb;
         return pr;
     };
+    // one sample: +-1 on its level of the lane's packed uint16 column (NaN-bin samples, b == nb, add zero)
     auto bump = [&](int b, int sgn) {
-        if (b < nb) {
-            const int k = lvl(b);
-            atomicAdd(&mycol[k >> 1], (unsigned)sgn * (1u << ((k & 1) * 16)));
-        }
+        int k = (b >> lsh) + loff;
+        k = k < 0 ? 0 : (k > lhi ? lhi : k);
+        unsigned v = (k & 1) ? one_hi : one_lo;
+        v = (b < nb) ? v : 0u;
+        atomicAdd(&mycol[k >> 1], sgn > 0 ? v : 0u - v);
     };
     auto apply_bucket = [&](const Pre& pr, int sgn) {
 #pragma unroll
         for (int u = 0; u < TB_PRE; ++u) bump(pr.b[u], sgn);
-        if (pr.nd > TB_PRE) {  // long buckets (many years): stream the rest, 4 loads in flight
+        if (pr.nd > TB_PRE) {  // long buckets (many years): stream the rest, 16 loads in flight
             const unsigned short* col = colbase + (size_t)pr.r0 * 16;
-            for (int r = TB_PRE; r < pr.nd; r += 4) {
+            int r = TB_PRE;
+            for (; r + 16 <= pr.nd; r += 16) {
+                int bb[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) bb[u] = (int)col[(size_t)(r + u) * 16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) bump(bb[u], sgn);
+            }
+            for (; r < pr.nd; r += 4) {
                 int bb[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) bb[u] = (r + u < pr.nd) ? (int)col[(size_t)(r + u) * 16] : nb;
@@ -1496,12 +1505,18 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         if (mode == 0) {
             fine = false;
             nlev = ngroups;
+            lsh = shift;
+            loff = 0;
+            lhi = ngroups - 1;
         } else {
             fine = true;
             B0 = g_base << shift;
             BW = ng << shift;
             if (B0 + BW > nb) BW = nb - B0;
             nlev = BW + 2;
+            lsh = 0;
+            loff = 1 - B0;
+            lhi = BW + 1;
         }
         const int nlp = (nlev + 1) >> 1;
         int hint = -1;
