@@ -36,6 +36,8 @@ struct marex_ctx {
     double total_ms[MAREX_K_COUNT] = {0};
     int64_t launches[MAREX_K_COUNT] = {0};
     int* shift_info = nullptr;  // device, SHIFT_INFO_WORDS ints: which dayofyear chunks the fast anomaly kernel takes
+    unsigned char* thr_scratch = nullptr;  // device, per-(tile, day, lane) state bytes of the 1024-thread threshold tiles
+    size_t thr_scratch_bytes = 0;
 };
 
 static int fail(marex_ctx* ctx, int code, const char* fmt, ...) {
@@ -108,6 +110,7 @@ extern "C" int marex_destroy(marex_ctx* ctx) {
     if (!ctx) return -1;
     drain_timers(ctx);
     if (ctx->shift_info) (void)hipFree(ctx->shift_info);
+    if (ctx->thr_scratch) (void)hipFree(ctx->thr_scratch);
     delete ctx;
     return 0;
 }
@@ -1253,19 +1256,29 @@ k_thresholds(const unsigned short* __restrict__ bins, long T_out, long C, int ny
 #define TB_LS 34
 #define TB_DMAX 32
 #define TB_PRE 8
+#ifndef TB_BATCH
+#define TB_BATCH 16
+#endif
 
 template <int P, int TC, int NT>
 __global__ void __launch_bounds__(NT)
 k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, int nx, int row0, int row1, int tiles_x,
            int Dd, int shift, int env_exact, int ablate, const int* __restrict__ doy_start,
            const float* __restrict__ first_anom, const float* __restrict__ centres, int nb, double q, int wd,
-           float lower_bound, float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats) {
+           float lower_bound, float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats,
+           unsigned char* __restrict__ gscratch, int coarse_pd) {
     constexpr int TR = NT / TC;
     constexpr int OR = TR - 2 * P, OC = TC - 2 * P;
     // lane-major level columns: TB_LS dwords (= 68 uint16 levels) per lane.  The stride 34 keeps 8-byte
     // alignment and makes 8-byte accesses of 32 consecutive lanes hit 64 distinct banks.
     __shared__ unsigned lev[NT * TB_LS];
-    __shared__ unsigned char gst[NT > 256 ? 16 : TB_DMAX][NT];  // the host limits Dd to 16 for 1024-thread tiles
+    // per (day of the block, lane) state byte; every thread touches only its own bytes.  256-thread tiles keep it
+    // in LDS; 1024-thread tiles (LDS is full of level columns) in a global scratch slab, which lifts the limit on Dd
+    __shared__ unsigned char gst_lds[NT > 256 ? 1 : TB_DMAX][NT];
+    unsigned char (*gst)[NT] = gst_lds;
+    if (NT > 256)
+        gst = reinterpret_cast<unsigned char (*)[NT]>(
+            gscratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)Dd * NT);
     __shared__ int s_gmin, s_gmax, s_unres;
 
     const int t = threadIdx.x;
@@ -1345,12 +1358,12 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         if (pr.nd > TB_PRE) {  // long buckets (many years): stream the rest, 16 loads in flight
             const unsigned short* col = colbase + (size_t)pr.r0 * 16;
             int r = TB_PRE;
-            for (; r + 16 <= pr.nd; r += 16) {
-                int bb[16];
+            for (; r + TB_BATCH <= pr.nd; r += TB_BATCH) {
+                int bb[TB_BATCH];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) bb[u] = (int)col[(size_t)(r + u) * 16];
+                for (int u = 0; u < TB_BATCH; ++u) bb[u] = (int)col[(size_t)(r + u) * 16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) bump(bb[u], sgn);
+                for (int u = 0; u < TB_BATCH; ++u) bump(bb[u], sgn);
             }
             for (; r < pr.nd; r += 4) {
                 int bb[4];
@@ -1501,7 +1514,9 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
     //   mode 1  fine levels, SPECULATIVE band (chosen from day 0): resolve what falls inside the band,
     //           flag the rest (254) for the exact path
     //   mode 2  fine levels, exact band g_base..: resolve the output-days whose group lies in the band
-    auto sweep = [&](int mode, int nd_pass, int ng) {
+    // init_pd < pd: day 0 of a coarse sweep sees only the 2*init_pd+1 central buckets -- good enough to PLACE the
+    // speculative band (a wrong guess only sends the block to the exact path), never used for a result
+    auto sweep = [&](int mode, int nd_pass, int ng, int init_pd) {
         if (mode == 0) {
             fine = false;
             nlev = ngroups;
@@ -1527,8 +1542,8 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
             if (dd == 0) {
                 for (int r = 0; r < TB_LS / 2; ++r) mycol2[r] = make_uint2(0u, 0u);
                 if (!(ablate & 4)) {
-                    Pre cur = load_bucket(((d - pd) % NDOY + NDOY) % NDOY);
-                    for (int o = -pd + 1; o <= pd; ++o) {
+                    Pre cur = load_bucket(((d - init_pd) % NDOY + NDOY) % NDOY);
+                    for (int o = -init_pd + 1; o <= init_pd; ++o) {
                         const Pre nxt = load_bucket(((d + o) % NDOY + NDOY) % NDOY);
                         apply_bucket(cur, +1);
                         cur = nxt;
@@ -1561,7 +1576,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
                         gst[dd][t] = (unsigned char)gg;
                         atomicMin(&s_gmin, gg);
                         atomicMax(&s_gmax, gg);
-                    } else {
+                    } else if (init_pd == pd) {
                         gst[dd][t] = 255;
                         thr[(size_t)d * C + cell] = nan_f();  // empty window
                     }
@@ -1619,7 +1634,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
     };
 
     __syncthreads();
-    sweep(0, 1, 0);  // coarse, day 0 only
+    sweep(0, 1, 0, (coarse_pd >= 0 && coarse_pd < pd) ? coarse_pd : pd);  // coarse, day 0 only
     int gmin = s_gmin, gmax = s_gmax;
     __syncthreads();
     if (!env_exact && gmax >= 0 && gmax - gmin + 1 <= gpp) {
@@ -1628,7 +1643,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         g_base = gmin - (spare + 1) / 2;
         if (g_base < 0) g_base = 0;
         if (g_base + gpp > ngroups) g_base = ngroups - gpp > 0 ? ngroups - gpp : 0;
-        sweep(1, ndays, gpp < ngroups ? gpp : ngroups);
+        sweep(1, ndays, gpp < ngroups ? gpp : ngroups, pd);
     } else if (t == 0) {
         s_unres = 1;
     }
@@ -1642,12 +1657,12 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
             s_gmax = -1;
         }
         __syncthreads();
-        sweep(0, ndays, 0);
+        sweep(0, ndays, 0, pd);
         gmin = s_gmin;
         gmax = s_gmax;
         for (g_base = gmin; g_base <= gmax; g_base += gpp) {
             const int ng = (gmax - g_base + 1) < gpp ? (gmax - g_base + 1) : gpp;
-            sweep(2, ndays, ng);
+            sweep(2, ndays, ng, pd);
         }
     }
     // statistics: wave reduction, one set of global atomics per wave
@@ -1706,11 +1721,24 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
         const int NT = big ? 1024 : 256;
         const int TR = (ny > 0 && p > 0) ? (big ? 32 : 16) : 1, TC = NT / TR;
         const int OR = TR - 2 * p, OC = TC - 2 * p;
-        int Dd = env_int("MAREX_THR_DD", big ? 16 : TB_DMAX);
-        if (Dd < 1 || Dd > (big ? 16 : TB_DMAX)) Dd = big ? 16 : TB_DMAX;
+        int Dd = env_int("MAREX_THR_DD", big ? 48 : TB_DMAX);
+        if (Dd < 1 || Dd > (big ? 128 : TB_DMAX)) Dd = big ? 48 : TB_DMAX;
         const int tiles_x = (nx + OC - 1) / OC, tiles_y = (row1 - row0 + OR - 1) / OR;
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((NDOY + Dd - 1) / Dd));
-#define MAREX_BAND_ARGS bins, (long)T_out, (long)C, ny, nx, row0, row1, tiles_x, Dd, shift, env_int("MAREX_THR_EXACT_PATH", 0), env_int("MAREX_THR_ABLATE", 0), doy_start, first_anom, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats
+        unsigned char* gscratch = nullptr;
+        if (big) {  // state bytes of the 1024-thread tiles
+            const size_t need = (size_t)grid.x * grid.y * (size_t)Dd * NT;
+            if (need > ctx->thr_scratch_bytes) {
+                if (ctx->thr_scratch) HIP_TRY(ctx, hipFree(ctx->thr_scratch));
+                ctx->thr_scratch = nullptr;
+                ctx->thr_scratch_bytes = 0;
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->thr_scratch, need));
+                ctx->thr_scratch_bytes = need;
+            }
+            gscratch = ctx->thr_scratch;
+        }
+        const int coarse_pd = env_int("MAREX_THR_COARSE_PD", 1);
+#define MAREX_BAND_ARGS bins, (long)T_out, (long)C, ny, nx, row0, row1, tiles_x, Dd, shift, env_int("MAREX_THR_EXACT_PATH", 0), env_int("MAREX_THR_ABLATE", 0), doy_start, first_anom, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats, gscratch, coarse_pd
         {
             LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
             if (TR == 1)
