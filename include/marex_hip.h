@@ -50,7 +50,8 @@ enum {
     MAREX_K_DETREND = 6,
     MAREX_K_EXACT = 7,
     MAREX_K_GLOBAL = 8,
-    MAREX_K_COUNT = 9
+    MAREX_K_STDNORM = 9,      /* day-of-year std, 30-day wrapped rolling RMS, anomaly / STD                 */
+    MAREX_K_COUNT = 10
 };
 
 int marex_abi_version(void);
@@ -180,6 +181,21 @@ int marex_global_threshold_f32(marex_ctx* ctx, const float* anom, int64_t T_out,
 /* extreme[t, c] = anom[t, c] >= thr[c] (comparison in float64, detect.py:2915) and the count of True */
 int marex_mask_ge_const_f32(marex_ctx* ctx, const float* anom, const double* thr, int64_t T_out, int64_t C,
                             uint8_t* extreme, unsigned long long* n_true);
+
+/* std_normalise branch of detrend_harmonic, part 1 (marEx/detect.py:2257-2273):
+ *   std_day[d, c]  = population standard deviation (ddof = 0) of anom[t, c] over the rows with dayofyear d + 1 --
+ *                    NaN when a term is NaN or the dayofyear never occurs; float64 two-pass (mean, then squared
+ *                    deviations, both summed in ascending time), one float64 sqrt, rounded to float32
+ *   std_roll[d, c] = float32 sqrt of the centred `window`-day mean of float32(std_day^2) on the wrapped dayofyear
+ *                    axis (offsets -window/2 .. window-1-window/2; float64 sum in ascending offset, / window,
+ *                    rounded to float32; NaN when a term is NaN)  -- the reference's `STD` variable (window = 30).
+ * doy_start / doy_rows: rows of `anom` grouped by dayofyear (int32 [367] / [T]).  std_day is caller workspace. */
+int marex_std_rolling_doy_f32(marex_ctx* ctx, const float* anom, int64_t T, int64_t C, const int32_t* doy_start,
+                              const int32_t* doy_rows, int window, float* std_day, float* std_roll);
+
+/* part 2 (detect.py:2275-2278): out[t, c] = anom[t, c] / (std_roll[doy(t), c] > 1e-10 ? std_roll : NaN), float32 division */
+int marex_div_doy_f32(marex_ctx* ctx, const float* anom, const float* std_roll, const int32_t* doy_start,
+                      const int32_t* doy_rows, int64_t T, int64_t C, float* out);
 
 /* out[c, r] = in[r, c]  (thresholds [366, C] -> the reference's (cells, dayofyear) order) */
 int marex_transpose_f32(marex_ctx* ctx, const float* in, int64_t rows, int64_t cols, float* out);

@@ -50,6 +50,8 @@ PROTOTYPES = {
     "marex_hobday_exact_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _f32, _f64, _i32, _p, _p]),
     "marex_global_threshold_f32": (_i32, [_p, _p, _i64, _i64, _f64, _i32, _p, _p, _i32, _f64, _f64, _p, _p, _p]),
     "marex_mask_ge_const_f32": (_i32, [_p, _p, _p, _i64, _i64, _p, _p]),
+    "marex_std_rolling_doy_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _p, _p]),
+    "marex_div_doy_f32": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _p]),
 }
 
 KERNEL_IDS = {
@@ -62,6 +64,7 @@ KERNEL_IDS = {
     "detrend": 6,
     "exact": 7,
     "global": 8,
+    "stdnorm": 9,
 }
 
 _lib: Optional[C.CDLL] = None

@@ -2398,6 +2398,99 @@ extern "C" int marex_mask_ge_const_f32(marex_ctx* ctx, const float* anom, const 
 // ------------------------------------------------------------------------------------------------
 // transpose (thresholds [366, C] -> [C, 366])
 // ------------------------------------------------------------------------------------------------
+// std_normalise (detect.py:2257-2278): day-of-year standard deviation, wrapped rolling RMS, division
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_doy_std(const float* __restrict__ anom, const int* __restrict__ doy_start, const int* __restrict__ doy_rows, long C,
+          float* __restrict__ std_day) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    const int d = blockIdx.y;
+    if (c >= C) return;
+    const int r0 = doy_start[d], r1 = doy_start[d + 1];
+    float res = nan_f();
+    if (r1 > r0) {
+        double sum = 0.0;
+        for (int r = r0; r < r1; ++r) sum += (double)anom[(size_t)doy_rows[r] * C + c];
+        const double mean = sum / (double)(r1 - r0);
+        double ss = 0.0;
+        for (int r = r0; r < r1; ++r) {  // second pass over the same few rows (L2 resident)
+            const double dv = (double)anom[(size_t)doy_rows[r] * C + c] - mean;
+            ss += dv * dv;
+        }
+        res = (float)sqrt(ss / (double)(r1 - r0));
+    }
+    std_day[(size_t)d * C + c] = res;
+}
+
+__global__ void __launch_bounds__(256)
+k_std_rolling(const float* __restrict__ std_day, long C, int window, float* __restrict__ std_roll) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    const int d = blockIdx.y;
+    if (c >= C) return;
+    const int lo = window / 2;
+    double acc = 0.0;
+    for (int k = 0; k < window; ++k) {
+        int dd = (d - lo + k) % NDOY;
+        if (dd < 0) dd += NDOY;
+        const float sd = std_day[(size_t)dd * C + c];
+        const float sq = sd * sd;
+        acc += (double)sq;
+    }
+    const float m = (float)(acc / (double)window);
+    std_roll[(size_t)d * C + c] = sqrtf(m);
+}
+
+__global__ void __launch_bounds__(256)
+k_div_doy(const float* __restrict__ anom, const float* __restrict__ std_roll, const int* __restrict__ doy_start,
+          const int* __restrict__ doy_rows, long C, float* __restrict__ out) {
+    const int dA = (int)blockIdx.y * NDOY / MASK_DOY_CHUNKS, dB = ((int)blockIdx.y + 1) * NDOY / MASK_DOY_CHUNKS;
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    for (int d = dA; d < dB; ++d) {
+        const float sd = std_roll[(size_t)d * C + c];
+        const float safe = sd > 1e-10f ? sd : nan_f();
+        const int r0 = doy_start[d], r1 = doy_start[d + 1];
+        for (int r = r0; r < r1; ++r) {
+            const size_t off = (size_t)doy_rows[r] * C + c;
+            out[off] = anom[off] / safe;
+        }
+    }
+}
+
+extern "C" int marex_std_rolling_doy_f32(marex_ctx* ctx, const float* anom, int64_t T, int64_t C,
+                                         const int32_t* doy_start, const int32_t* doy_rows, int window,
+                                         float* std_day, float* std_roll) {
+    if (!ctx) return -1;
+    if (!anom || !doy_start || !doy_rows || !std_day || !std_roll || T <= 0 || C <= 0)
+        return fail(ctx, -1, "marex_std_rolling_doy_f32: null pointer or empty shape");
+    if (window < 1 || window > NDOY) return fail(ctx, -1, "marex_std_rolling_doy_f32: window must be in 1..366");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((C + 255) / 256), NDOY);
+    {
+        LaunchTimer lt(ctx, MAREX_K_STDNORM);
+        hipLaunchKernelGGL(k_doy_std, grid, dim3(256), 0, ctx->stream, anom, doy_start, doy_rows, (long)C, std_day);
+        hipLaunchKernelGGL(k_std_rolling, grid, dim3(256), 0, ctx->stream, std_day, (long)C, window, std_roll);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int marex_div_doy_f32(marex_ctx* ctx, const float* anom, const float* std_roll, const int32_t* doy_start,
+                                 const int32_t* doy_rows, int64_t T, int64_t C, float* out) {
+    if (!ctx) return -1;
+    if (!anom || !std_roll || !doy_start || !doy_rows || !out || T <= 0 || C <= 0)
+        return fail(ctx, -1, "marex_div_doy_f32: null pointer or empty shape");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((C + 255) / 256), MASK_DOY_CHUNKS);
+    {
+        LaunchTimer lt(ctx, MAREX_K_STDNORM);
+        hipLaunchKernelGGL(k_div_doy, grid, dim3(256), 0, ctx->stream, anom, std_roll, doy_start, doy_rows, (long)C, out);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ in, long rows, long cols,
                                                    float* __restrict__ out) {
     __shared__ float tile[32][33];

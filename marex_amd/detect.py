@@ -428,7 +428,7 @@ def _warn_threshold_range(stats: Dict[str, float], bt: binning.BinTable, max_ano
 
 
 def _extremes_core(eng, a, field: _Field, method_extreme, threshold_percentile, window_days_hobday, ws_eff,
-                   method_percentile, bt: Optional[binning.BinTable], max_anomaly):
+                   method_percentile, bt: Optional[binning.BinTable], max_anomaly, wsp=None):
     """Threshold + mask stage on the device.  Returns (extreme uint8 [T', C], thresholds (host layout), dims tag)."""
     cal, dcal = a["cal"], a["dcal"]
     if method_extreme == "hobday_extreme":
@@ -508,11 +508,6 @@ def preprocess_data(
 
     dimensions, coordinates = _infer_dims_coords(da, dimensions, coordinates)
     _check_reference_period_allowed(reference_period, method_anomaly)
-    if std_normalise and method_anomaly == "detrend_harmonic":
-        raise ConfigurationError(
-            "std_normalise=True is not available on the device path yet",
-            details="the 30-day rolling STD normalisation (detect.py:2257-2293) is listed as a next step (SURVEY.md 8f)",
-        )
     if method_anomaly not in _ANOMALY_METHODS:
         raise ConfigurationError(
             f"Unknown anomaly method '{method_anomaly}'",
@@ -541,6 +536,19 @@ def preprocess_data(
     ext, thr, thr_kind, n_true = _extremes_core(
         eng, a, field, method_extreme, threshold_percentile, window_days_hobday, ws_eff, method_percentile, bt, max_anomaly
     )
+    # standardised anomalies and their own extremes (detect.py:2257-2293, 686-715): detrend_harmonic only
+    stn = None
+    if std_normalise and method_anomaly == "detrend_harmonic":
+        logger.info("Processing standardised anomalies for extreme identification")
+        sn = eng.std_normalise(a["anom"], a["dcal"])
+        a_stn = {"anom": sn["dat_stn"], "cal": cal, "dcal": a["dcal"], "bins": None}
+        if need_bins is not None:
+            a_stn["bins"] = eng.digitize(sn["dat_stn"], a["dcal"], bt, wsp={})
+        ext_s, thr_s, kind_s, _ = _extremes_core(
+            eng, a_stn, field, method_extreme, threshold_percentile, window_days_hobday, ws_eff, method_percentile, bt,
+            max_anomaly, wsp={},
+        )
+        stn = (sn, ext_s, thr_s, kind_s, eng.transpose(sn["STD"], name="std_cells_major"))
     eng.sync()
 
     time_out = field.time[cal.kept]
@@ -557,6 +565,18 @@ def preprocess_data(
         ds["thresholds"] = field.labelled(thr_np, doy_axis)
     else:
         ds["thresholds"] = field.labelled(thr_np, None)
+    if stn is not None:
+        sn, ext_s, thr_s, kind_s, std_t = stn
+        ds["dat_stn"] = field.labelled(sn["dat_stn"].cpu().numpy(), tlead)
+        ds["STD"] = field.labelled(std_t.cpu().numpy(), None, doy_axis)  # flox appends the group dim: (*space, dayofyear)
+        ds["extreme_events_stn"] = field.labelled(ext_s.cpu().numpy().astype(bool), tlead)
+        ts_np = thr_s.cpu().numpy()
+        if kind_s == "doy_last":
+            ds["thresholds_stn"] = field.labelled(ts_np, None, doy_axis)
+        elif kind_s == "doy_first":
+            ds["thresholds_stn"] = field.labelled(ts_np, doy_axis)
+        else:
+            ds["thresholds_stn"] = field.labelled(ts_np, None)
     if neighbours is not None:
         ds["neighbours"] = neighbours.astype(np.int32)
     if cell_areas is not None:
@@ -635,6 +655,12 @@ def compute_normalised_anomaly(
     ds = Dataset()
     ds["dat_anomaly"] = field.labelled(anom, (field.tdim, field.time))
     ds["mask"] = field.labelled(a["mask"].cpu().numpy().astype(bool), None)
+    if std_normalise and method_anomaly == "detrend_harmonic":  # detect.py:2257-2293
+        sn = eng.std_normalise(a["anom"], a["dcal"])
+        std_t = eng.transpose(sn["STD"], name="std_cells_major")
+        eng.sync()
+        ds["dat_stn"] = field.labelled(sn["dat_stn"].cpu().numpy(), (field.tdim, field.time))
+        ds["STD"] = field.labelled(std_t.cpu().numpy(), None, ("dayofyear", np.arange(1, calendar.N_DOY + 1)))
     return ds
 
 

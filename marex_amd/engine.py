@@ -369,6 +369,27 @@ class HotPath:
         return res
 
     # ------------------------------------------------------------------ stage a9 exact Hobday
+    def std_normalise(self, anom: torch.Tensor, dcal: DeviceCalendar, window: int = 30,
+                      wsp: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+        """``dat_stn`` and ``STD`` of the std_normalise branch (detect.py:2257-2278): day-of-year standard deviation,
+        wrapped ``window``-day rolling RMS of it, anomaly / STD.  ``STD`` is returned dayofyear-major ``[366, C]``."""
+        self._bind_stream()
+        T, Cn = anom.shape
+        std_day = self._buf(wsp, "std_day", (N_DOY, Cn), torch.float32, self.device)
+        std_roll = self._buf(wsp, "std_roll", (N_DOY, Cn), torch.float32, self.device)
+        out = self._buf(wsp, "dat_stn", (T, Cn), torch.float32, self.device)
+        rc = self.lib.marex_std_rolling_doy_f32(
+            self.ctx.handle, anom.data_ptr(), T, Cn, dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), int(window),
+            std_day.data_ptr(), std_roll.data_ptr(),
+        )
+        self.ctx.check(rc, "marex_std_rolling_doy_f32")
+        rc = self.lib.marex_div_doy_f32(
+            self.ctx.handle, anom.data_ptr(), std_roll.data_ptr(), dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(),
+            T, Cn, out.data_ptr(),
+        )
+        self.ctx.check(rc, "marex_div_doy_f32")
+        return {"dat_stn": out, "STD": std_roll}
+
     def hobday_thresholds_exact(self, anom: torch.Tensor, dcal: DeviceCalendar, percentile: float, wd: int,
                                 wsp: Optional[dict] = None) -> torch.Tensor:
         """``np.nanpercentile`` per (dayofyear window, cell), float32, layout ``[366, C]`` (detect.py:1921-1956)."""

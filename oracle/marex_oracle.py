@@ -527,3 +527,45 @@ def preprocess_arrays(
     else:
         raise ValueError(method_extreme)
     return {"dat_anomaly": anom, "mask": mask, "thresholds": thr, "extreme_events": extremes, "stats": stats}
+
+
+def std_normalise(anom: np.ndarray, doy: np.ndarray, window: int = 30):
+    """``std_normalise`` branch of detrend_harmonic (marEx/detect.py:2257-2278).
+
+    * ``std_day[d]`` = population standard deviation (flox ``func="std"``, ddof 0, NaN-propagating, NaN for a
+      dayofyear that never occurs) of the anomalies with dayofyear ``d+1``.  Contract: float64 two-pass -- mean from
+      a sequential sum in ascending time, then the sequential sum of squared deviations, one float64 sqrt, rounded
+      to float32 (the reference's flox/float32 reduction differs in the last bits and with its chunking).
+    * ``STD[d]`` = sqrt of the centred ``window``-day mean of ``float32(std_day**2)`` on the wrapped dayofyear axis:
+      ``pad(16, wrap) -> rolling(30, center=True).mean() -> isel(16:382)`` = offsets ``-window//2 .. window-1-window//2``;
+      float64 sequential sum, ``/ window``, rounded to float32, float32 sqrt.
+    * ``dat_stn = anom / where(STD > 1e-10, STD, NaN)[dayofyear]`` (float32 division).
+
+    Returns ``(dat_stn [T, C] float32, STD [366, C] float32)``.
+    """
+    anom = np.asarray(anom, dtype=np.float32)
+    doy = np.asarray(doy)
+    C = anom.shape[1]
+    std_day = np.full((366, C), np.nan, dtype=np.float32)
+    for d in range(366):
+        rows = np.flatnonzero(doy == d + 1)
+        if rows.size == 0:
+            continue
+        x = anom[rows].astype(np.float64)
+        n = float(rows.size)
+        with np.errstate(invalid="ignore"):
+            mean = np.cumsum(x, axis=0)[-1] / n
+            dv = x - mean
+            ss = np.cumsum(dv * dv, axis=0)[-1]
+            std_day[d] = np.sqrt(ss / n).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        sq = std_day * std_day  # float32
+        lo = window // 2
+        acc = np.zeros((366, C), dtype=np.float64)
+        idx = np.arange(366)
+        for k in range(window):
+            acc = acc + sq[(idx - lo + k) % 366].astype(np.float64)
+        std_roll = np.sqrt((acc / float(window)).astype(np.float32))
+        safe = np.where(std_roll > np.float32(1e-10), std_roll, np.float32(np.nan)).astype(np.float32)
+        dat_stn = (anom / safe[np.asarray(doy, dtype=np.int64) - 1]).astype(np.float32)
+    return dat_stn, std_roll
