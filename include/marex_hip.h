@@ -55,6 +55,8 @@ enum {
 };
 
 int marex_abi_version(void);
+/* A context owns small device scratch buffers that its launches share: use one context per (device, host thread,
+ * stream); launches through one context are stream-ordered and must not overlap on different streams. */
 int marex_create(int device, marex_ctx** out);
 int marex_destroy(marex_ctx* ctx);
 const char* marex_last_error(marex_ctx* ctx);

@@ -1328,8 +1328,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
     int B0 = 0, BW = 0, nlev = ngroups;
     int lsh = shift, loff = 0, lhi = ngroups - 1;
     const unsigned short* colbase = bins + bins_index(0, cell_valid ? cell : 0, T_out);  // rows are 16 elements apart
-    // Lanes outside the grid stream cell 0 (valid memory, uniform control flow) but add zeros.
-    const unsigned one_lo = cell_valid ? 1u : 0u, one_hi = cell_valid ? 0x10000u : 0u;
+    // Lanes outside the grid stream cell 0 (valid memory, uniform loop bounds); their bumps are masked off.
     // first TB_PRE samples of a dayofyear bucket of this lane's cell, kept in registers
     struct Pre {
         int b[TB_PRE];
@@ -1344,33 +1343,53 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         for (int u = 0; u < TB_PRE; ++u) pr.b[u] = (u < pr.nd) ? (int)col[(size_t)u * 16] : nb;
         return pr;
     };
-    // one sample: +-1 on its level of the lane's packed uint16 column (NaN-bin samples, b == nb, add zero)
+    // One sample: +-1 on its level of the lane's packed uint16 column -- 8 vector instructions + 1 LDS atomic:
+    //   k = med3((b >> lsh) + loff, 0, lhi); odd = k & 1; byte offset in the column = 2 * (k - odd);
+    //   value = +-(1 << 16 * odd) as a 24-bit multiply-add; NaN-bin samples (b == nb) add zero.
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    const unsigned col_lds = (unsigned)(size_t)(lds_u32*)mycol;  // 32-bit LDS byte address of the lane's column
+    const int mul_p = 65535, mul_n = -65535, one_p = 1, one_n = -1;
     auto bump = [&](int b, int sgn) {
         int k = (b >> lsh) + loff;
-        k = k < 0 ? 0 : (k > lhi ? lhi : k);
-        unsigned v = (k & 1) ? one_hi : one_lo;
-        v = (b < nb) ? v : 0u;
-        atomicAdd(&mycol[k >> 1], sgn > 0 ? v : 0u - v);
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(k) : "v"(k), "v"(lhi));
+        const int odd = k & 1;
+        const int even = k & ~1;
+        unsigned addr;
+        asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(addr) : "v"(even), "v"(col_lds));
+        int v;
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(v) : "v"(odd), "v"(sgn > 0 ? mul_p : mul_n), "v"(sgn > 0 ? one_p : one_n));
+        v = (b < nb) ? v : 0;
+        __hip_atomic_fetch_add((lds_u32*)(size_t)addr, (unsigned)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     auto apply_bucket = [&](const Pre& pr, int sgn) {
+        if (cell_valid) {
 #pragma unroll
-        for (int u = 0; u < TB_PRE; ++u) bump(pr.b[u], sgn);
-        if (pr.nd > TB_PRE) {  // long buckets (many years): stream the rest, 16 loads in flight
+            for (int u = 0; u < TB_PRE; ++u) bump(pr.b[u], sgn);
+        }
+        if (pr.nd > TB_PRE) {  // long buckets (many years): stream the rest, TB_BATCH loads in flight
             const unsigned short* col = colbase + (size_t)pr.r0 * 16;
             int r = TB_PRE;
             for (; r + TB_BATCH <= pr.nd; r += TB_BATCH) {
                 int bb[TB_BATCH];
 #pragma unroll
                 for (int u = 0; u < TB_BATCH; ++u) bb[u] = (int)col[(size_t)(r + u) * 16];
+                if (cell_valid) {
 #pragma unroll
-                for (int u = 0; u < TB_BATCH; ++u) bump(bb[u], sgn);
+                    for (int u = 0; u < TB_BATCH; ++u) bump(bb[u], sgn);
+                }
             }
-            for (; r < pr.nd; r += 4) {
-                int bb[4];
+            if (r < pr.nd) {  // last, partial batch in ONE round trip: clamped row index, surplus samples add zero
+                int bb[TB_BATCH];
+                const int last = pr.nd - 1;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) bb[u] = (r + u < pr.nd) ? (int)col[(size_t)(r + u) * 16] : nb;
+                for (int u = 0; u < TB_BATCH; ++u) {
+                    const int rr = r + u < last ? r + u : last;  // uniform
+                    bb[u] = (int)col[(size_t)rr * 16];
+                }
+                if (cell_valid) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) bump(bb[u], sgn);
+                    for (int u = 0; u < TB_BATCH; ++u) bump(r + u <= last ? bb[u] : nb, sgn);
+                }
             }
         }
     };
@@ -1717,9 +1736,12 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
         // long dayofyear buckets (many years) make the kernel sample-streaming bound: the big tile re-streams
         // 1.31x instead of 1.78x halo cells per output cell (measured 17.4 vs 23.3 ms on an 85-year band)
         const int tile_pref = env_int("MAREX_THR_TILE", max_bucket >= 24 ? 32 : 16);
-        const bool big = (ny > 0 && p > 0) && tile_pref == 32 && (row1 - row0) >= 16 && nx >= 16;
-        const int NT = big ? 1024 : 256;
-        const int TR = (ny > 0 && p > 0) ? (big ? 32 : 16) : 1, TC = NT / TR;
+        // tile_pref 32: 32x32 cells / 1024 threads (one workgroup per CU); 3216: 32 wide x 16 tall / 512 threads (two
+        // independent workgroups per CU); 16: 16x16 / 256 threads
+        const bool big = (ny > 0 && p > 0) && (tile_pref == 32 || tile_pref == 3216) && (row1 - row0) >= 16 && nx >= 16;
+        const bool half = big && tile_pref == 3216;
+        const int NT = big ? (half ? 512 : 1024) : 256;
+        const int TR = (ny > 0 && p > 0) ? (big ? (half ? 16 : 32) : 16) : 1, TC = NT / TR;
         const int OR = TR - 2 * p, OC = TC - 2 * p;
         int Dd = env_int("MAREX_THR_DD", big ? 48 : TB_DMAX);
         if (Dd < 1 || Dd > (big ? 128 : TB_DMAX)) Dd = big ? 48 : TB_DMAX;
@@ -1743,6 +1765,8 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
             LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
             if (TR == 1)
                 hipLaunchKernelGGL((k_thr_band<0, 256, 256>), grid, dim3(256), 0, ctx->stream, MAREX_BAND_ARGS);
+            else if (half && p == 2)
+                hipLaunchKernelGGL((k_thr_band<2, 32, 512>), grid, dim3(512), 0, ctx->stream, MAREX_BAND_ARGS);
             else if (big && p == 1)
                 hipLaunchKernelGGL((k_thr_band<1, 32, 1024>), grid, dim3(1024), 0, ctx->stream, MAREX_BAND_ARGS);
             else if (big && p == 2)
