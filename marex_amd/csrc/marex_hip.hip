@@ -1280,9 +1280,14 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         gst = reinterpret_cast<unsigned char (*)[NT]>(
             gscratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)Dd * NT);
     __shared__ int s_gmin, s_gmax, s_unres;
+    __shared__ unsigned tot_s[NT];  // per tile cell: number of samples in its window (top of the cumulative column)
 
     const int t = threadIdx.x;
-    const int tr = t / TC, tc = t - tr * TC;
+    // lane -> tile cell: rows are rotated by P so that the output rows P .. TR-P-1 fill the FIRST waves completely and
+    // the halo rows share the last one(s), which then skip the per-output phase (a 16x16 tile with P = 2: three waves
+    // at 48/64 output lanes + one idle, instead of 24+48+48+24 over four)
+    const int tc = t % TC;
+    const int tr = (TR > 1) ? (t / TC + P) % TR : 0;
     const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
     const int jt0 = row0 + ty * OR, it0 = tx * OC;
     const int j = (ny > 0) ? jt0 - P + tr : 0;
@@ -1313,7 +1318,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         return;
     }
 
-    unsigned* mycol = &lev[t * TB_LS];
+    unsigned* mycol = &lev[(tr * TC + tc) * TB_LS];  // columns are indexed by tile cell: neighbour offsets stay linear
     uint2* mycol2 = reinterpret_cast<uint2*>(mycol);
     for (int r = 0; r < TB_LS / 2; ++r) mycol2[r] = make_uint2(0u, 0u);
     if (t == 0) {
@@ -1394,7 +1399,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         }
     };
     // in-place inclusive prefix sum / its inverse over the lane's column, four levels per 8-byte access
-    auto prefix = [&](int nlp) {
+    auto prefix = [&](int nlp) -> unsigned {
         unsigned run = 0;
         const int n2 = (nlp + 1) >> 1;
 #pragma unroll 4
@@ -1405,6 +1410,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
             run = a3;
             mycol2[i] = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
         }
+        return run;  // all samples of the window (levels past the last used one are empty)
     };
     auto unprefix = [&](int nlp) {
         unsigned prev = 0;
@@ -1426,6 +1432,16 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         for (int dr = -P; dr <= P; ++dr)
 #pragma unroll
             for (int dc = -P; dc <= P; ++dc) sum += (int)((base[(dr * TC + dc) * TB_LS] >> sh16) & 0xFFFFu);
+        return sum;
+    };
+    // number of samples in the pooled window: the per-cell totals published by the column pass
+    auto pooled_tot = [&]() {
+        const unsigned* base = &tot_s[tr * TC + tc];
+        int sum = 0;
+#pragma unroll
+        for (int dr = -P; dr <= P; ++dr)
+#pragma unroll
+            for (int dc = -P; dc <= P; ++dc) sum += (int)base[dr * TC + dc];
         return sum;
     };
     // pooled cumulative counts at the EIGHT levels start .. start+7 (start % 4 == 0, start <= 60): two 8-byte
@@ -1576,7 +1592,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
                     apply_bucket(pout, -1);
                 }
             }
-            if (!(ablate & 2)) prefix(nlp);
+            if (!(ablate & 2)) tot_s[tr * TC + tc] = prefix(nlp);
             if (dd + 1 < nd_pass && !(ablate & 4)) {
                 pin = load_bucket((d + 1 + pd) % NDOY);
                 pout = load_bucket(((d - pd) % NDOY + NDOY) % NDOY);
@@ -1586,7 +1602,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
             const int g = (ablate & 1) ? 255 : gst[dd][t];
             if (mode == 0) {
                 if (g == 254) {
-                    const int tot = pooled(nlev - 1);
+                    const int tot = pooled_tot();
                     if (tot > 0) {
                         int ck, cb;
                         int gg = find_level(hint, 0, nlev, q * (double)tot, false, ck, cb);
@@ -1602,7 +1618,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
                 }
             } else if (mode == 1) {
                 if (g != 255) {
-                    const int tot = pooled(nlev - 1);
+                    const int tot = pooled_tot();
                     if (tot > 0) {
                         const double qpos = q * (double)tot;
                         if (hint < 0 && g < 254) hint = ((g - g_base) << shift) + 1 + (gsz >> 1);
@@ -1626,7 +1642,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
                 }
             } else {
                 if (g < 254 && g >= g_base && g < g_base + ng) {
-                    const int tot = pooled(nlev - 1);
+                    const int tot = pooled_tot();
                     const double qpos = q * (double)tot;
                     // the quantile bin lies inside group g: levels klo .. khi-1 of this band
                     const int klo = ((g - g_base) << shift) + 1;
