@@ -152,7 +152,9 @@ int marex_digitize_f32(marex_ctx* ctx, const float* anom, int64_t T, int64_t C, 
  * Polynomial / harmonic detrend (detect.py:2143-2224).  pmodel[T, n_coef] = pinv(model) and
  * model_t[T, n_coef] = model^T, float64, computed on the host (marex_amd/calendar.py:detrend_model).
  * out = x - fl32(model^T (pmodel^T x)), minus its time mean when force_zero_mean.  mask / invalid_count
- * are written (not accumulated) when given.
+ * are written (not accumulated) when given.  The two reductions over time are float64 partial sums over blocks of
+ * 1024 consecutive timesteps (ascending t) combined in ascending block order -- the order oracle.detrend_anomaly
+ * fixes (the reference's BLAS order is unspecified).  Scratch lives in the context.
  */
 int marex_detrend_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
                       const double* model_t, int n_coef, int force_zero_mean, float* out, uint8_t* mask,

@@ -38,6 +38,8 @@ struct marex_ctx {
     int* shift_info = nullptr;  // device, SHIFT_INFO_WORDS ints: which dayofyear chunks the fast anomaly kernel takes
     unsigned char* thr_scratch = nullptr;  // device, per-(tile, day, lane) state bytes of the 1024-thread threshold tiles
     size_t thr_scratch_bytes = 0;
+    unsigned char* detrend_scratch = nullptr;  // device, partial sums / coefficients / means of the detrend reductions
+    size_t detrend_scratch_bytes = 0;
 };
 
 static int fail(marex_ctx* ctx, int code, const char* fmt, ...) {
@@ -111,6 +113,7 @@ extern "C" int marex_destroy(marex_ctx* ctx) {
     drain_timers(ctx);
     if (ctx->shift_info) (void)hipFree(ctx->shift_info);
     if (ctx->thr_scratch) (void)hipFree(ctx->thr_scratch);
+    if (ctx->detrend_scratch) (void)hipFree(ctx->detrend_scratch);
     delete ctx;
     return 0;
 }
@@ -2037,41 +2040,103 @@ extern "C" int marex_digitize_f32(marex_ctx* ctx, const float* anom, int64_t T, 
 // The model tables are tiny ([T, n_coef] float64) and read through the scalar cache (uniform address).
 // ------------------------------------------------------------------------------------------------
 #define DETREND_MAXC 12
+#define DETREND_TBLOCK 1024  // timesteps per partial sum (arithmetic contract, oracle.DETREND_TBLOCK)
+
+// Reductions over time are split into blocks of DETREND_TBLOCK timesteps so that the grid is (cell blocks x time
+// blocks) instead of one thread walking 36 500 rows: float64 partial sums per block in ascending t, combined in
+// ascending block order -- a fixed order, mirrored by the oracle.
 __global__ void __launch_bounds__(256)
-k_detrend(const float* __restrict__ x, long T, long C, const double* __restrict__ pmodel /*[T][n]*/,
-          const double* __restrict__ model_t /*[T][n]*/, int n_coef, int force_zero_mean, float* __restrict__ out,
-          unsigned char* __restrict__ mask, int* __restrict__ invalid_count) {
+k_detrend_partial(const float* __restrict__ x, long T, long C, const double* __restrict__ pmodel /*[T][n]*/, int n_coef,
+                  double* __restrict__ partial /*[ntb][n][C]*/, int* __restrict__ invalid_count) {
     const long c = (long)blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    double coef[DETREND_MAXC];
+    const long t0 = (long)blockIdx.y * DETREND_TBLOCK;
+    const long t1 = t0 + DETREND_TBLOCK < T ? t0 + DETREND_TBLOCK : T;
+    double acc[DETREND_MAXC];
 #pragma unroll
-    for (int k = 0; k < DETREND_MAXC; ++k) coef[k] = 0.0;
+    for (int k = 0; k < DETREND_MAXC; ++k) acc[k] = 0.0;
     int n_invalid = 0;
-    for (long t = 0; t < T; ++t) {
+#pragma unroll 4
+    for (long t = t0; t < t1; ++t) {
         const float v = x[(size_t)t * C + c];
-        if (!finite_f(v)) ++n_invalid;
+        n_invalid += finite_f(v) ? 0 : 1;
         const double vd = (double)v;
         const double* pm = pmodel + (size_t)t * n_coef;
 #pragma unroll
         for (int k = 0; k < DETREND_MAXC; ++k)
-            if (k < n_coef) coef[k] += pm[k] * vd;
+            if (k < n_coef) acc[k] += pm[k] * vd;
+    }
+    for (int k = 0; k < n_coef; ++k) partial[((size_t)blockIdx.y * n_coef + k) * C + c] = acc[k];
+    if (invalid_count && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
+}
+
+__global__ void __launch_bounds__(256)
+k_detrend_combine(const float* __restrict__ x, long C, int ntb, int n_coef, const double* __restrict__ partial,
+                  double* __restrict__ coef /*[n][C]*/, unsigned char* __restrict__ mask) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    for (int k = 0; k < n_coef; ++k) {
+        double s = 0.0;
+        for (int b = 0; b < ntb; ++b) s += partial[((size_t)b * n_coef + k) * C + c];
+        coef[(size_t)k * C + c] = s;
     }
     if (mask) mask[c] = finite_f(x[c]) ? 1 : 0;
-    if (invalid_count) invalid_count[c] = n_invalid;
+}
+
+__global__ void __launch_bounds__(256)
+k_detrend_resid(const float* __restrict__ x, long T, long C, const double* __restrict__ model_t /*[T][n]*/, int n_coef,
+                const double* __restrict__ coef, float* __restrict__ out, double* __restrict__ psum /*[ntb][C]*/) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long t0 = (long)blockIdx.y * DETREND_TBLOCK;
+    const long t1 = t0 + DETREND_TBLOCK < T ? t0 + DETREND_TBLOCK : T;
+    double cf[DETREND_MAXC];
+#pragma unroll
+    for (int k = 0; k < DETREND_MAXC; ++k) cf[k] = k < n_coef ? coef[(size_t)k * C + c] : 0.0;
     double sum = 0.0;
-    for (long t = 0; t < T; ++t) {
+#pragma unroll 4
+    for (long t = t0; t < t1; ++t) {
         const double* mt = model_t + (size_t)t * n_coef;
         double trend = 0.0;
 #pragma unroll
         for (int k = 0; k < DETREND_MAXC; ++k)
-            if (k < n_coef) trend += mt[k] * coef[k];
+            if (k < n_coef) trend += mt[k] * cf[k];
         const float r = x[(size_t)t * C + c] - (float)trend;
         out[(size_t)t * C + c] = r;
         sum += (double)r;
     }
-    if (force_zero_mean) {
-        const float mean = (float)(sum / (double)T);
-        for (long t = 0; t < T; ++t) out[(size_t)t * C + c] -= mean;
+    psum[(size_t)blockIdx.y * C + c] = sum;
+}
+
+__global__ void __launch_bounds__(256)
+k_detrend_mean(long T, long C, int ntb, const double* __restrict__ psum, float* __restrict__ mean) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < ntb; ++b) s += psum[(size_t)b * C + c];
+    mean[c] = (float)(s / (double)T);
+}
+
+__global__ void __launch_bounds__(256)
+k_detrend_sub(long T, long C, const float* __restrict__ mean, float* __restrict__ out) {
+    const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= C) return;
+    const long t0 = (long)blockIdx.y * 64;
+    const long t1 = t0 + 64 < T ? t0 + 64 : T;
+    if (c + 4 <= C && (C & 3) == 0) {
+        const float4 m = *reinterpret_cast<const float4*>(mean + c);
+        for (long t = t0; t < t1; ++t) {
+            float4* p = reinterpret_cast<float4*>(out + (size_t)t * C + c);
+            float4 v = *p;
+            v.x -= m.x;
+            v.y -= m.y;
+            v.z -= m.z;
+            v.w -= m.w;
+            *p = v;
+        }
+    } else {
+        for (long t = t0; t < t1; ++t)
+            for (long cc = c; cc < C && cc < c + 4; ++cc) out[(size_t)t * C + cc] -= mean[cc];
     }
 }
 
@@ -2082,10 +2147,34 @@ extern "C" int marex_detrend_f32(marex_ctx* ctx, const float* x, int64_t T, int6
     if (!x || !pmodel || !model_t || !out || T <= 0 || C <= 0) return fail(ctx, -1, "marex_detrend_f32: null pointer or empty shape");
     if (n_coef < 1 || n_coef > DETREND_MAXC) return fail(ctx, -4, "marex_detrend_f32: n_coef must be in 1..%d", DETREND_MAXC);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int ntb = (int)((T + DETREND_TBLOCK - 1) / DETREND_TBLOCK);
+    // scratch: partial [ntb][n][C] f64 (reused as psum [ntb][C]) + coef [n][C] f64 + mean [C] f32
+    const size_t need = ((size_t)ntb * n_coef + n_coef + 1) * (size_t)C * sizeof(double);
+    if (need > ctx->detrend_scratch_bytes) {
+        if (ctx->detrend_scratch) HIP_TRY(ctx, hipFree(ctx->detrend_scratch));
+        ctx->detrend_scratch = nullptr;
+        ctx->detrend_scratch_bytes = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->detrend_scratch, need));
+        ctx->detrend_scratch_bytes = need;
+    }
+    double* partial = reinterpret_cast<double*>(ctx->detrend_scratch);
+    double* coef = partial + (size_t)ntb * n_coef * C;
+    float* mean = reinterpret_cast<float*>(coef + (size_t)n_coef * C);
+    if (invalid_count) HIP_TRY(ctx, hipMemsetAsync(invalid_count, 0, (size_t)C * sizeof(int), ctx->stream));
+    const unsigned ncb = (unsigned)((C + 255) / 256);
     {
         LaunchTimer lt(ctx, MAREX_K_DETREND);
-        hipLaunchKernelGGL(k_detrend, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, ctx->stream, x, (long)T, (long)C,
-                           pmodel, model_t, n_coef, force_zero_mean, out, mask, invalid_count);
+        hipLaunchKernelGGL(k_detrend_partial, dim3(ncb, ntb), dim3(256), 0, ctx->stream, x, (long)T, (long)C, pmodel, n_coef,
+                           partial, invalid_count);
+        hipLaunchKernelGGL(k_detrend_combine, dim3(ncb), dim3(256), 0, ctx->stream, x, (long)C, ntb, n_coef, partial, coef,
+                           mask);
+        hipLaunchKernelGGL(k_detrend_resid, dim3(ncb, ntb), dim3(256), 0, ctx->stream, x, (long)T, (long)C, model_t, n_coef,
+                           coef, out, partial);
+        if (force_zero_mean) {
+            hipLaunchKernelGGL(k_detrend_mean, dim3(ncb), dim3(256), 0, ctx->stream, (long)T, (long)C, ntb, partial, mean);
+            hipLaunchKernelGGL(k_detrend_sub, dim3((unsigned)((C / 4 + 256) / 256), (unsigned)((T + 63) / 64)), dim3(256), 0,
+                               ctx->stream, (long)T, (long)C, mean, out);
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;

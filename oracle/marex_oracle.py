@@ -169,18 +169,27 @@ def fixed_baseline_anomaly(
 # --------------------------------------------------------------------------------------
 # a12 polynomial / harmonic detrend                                  detect.py:2061-2296
 # --------------------------------------------------------------------------------------
-def detrend_anomaly(x: np.ndarray, model: np.ndarray, pmodel: np.ndarray, force_zero_mean: bool) -> np.ndarray:
-    """``coef = pmodel^T x`` (float64, ascending t), ``resid = x - fl32(model^T coef)``, optional ``- mean_t``.
+DETREND_TBLOCK = 1024  # timesteps per partial sum of the detrend reductions (part of the arithmetic contract)
 
-    The reference's BLAS summation order is unspecified, so this stage is tolerance-only.
-    The time mean is accumulated in float64 (ascending t) and rounded to float32 once.
+
+def detrend_anomaly(x: np.ndarray, model: np.ndarray, pmodel: np.ndarray, force_zero_mean: bool) -> np.ndarray:
+    """``coef = pmodel^T x`` (float64), ``resid = x - fl32(model^T coef)``, optional ``- mean_t``.
+
+    The reference's BLAS summation order is unspecified, so against the reference this stage is tolerance-only
+    (SURVEY A.9).  Contract of the two reductions over time (what the kernels reproduce bit for bit): partial sums
+    over blocks of ``DETREND_TBLOCK`` consecutive timesteps -- float64, ascending t, starting from 0.0 -- combined
+    in ascending block order starting from 0.0.  The trend is the float64 sum over coefficients in ascending k,
+    rounded to float32 once; the time mean is rounded to float32 once.
     """
     x = np.asarray(x, dtype=np.float32)
     T, C = x.shape
     n_coef = model.shape[0]
     coef = np.zeros((n_coef, C), dtype=np.float64)
-    for t in range(T):
-        coef += pmodel[t][:, None] * x[t].astype(np.float64)[None, :]
+    for t0 in range(0, T, DETREND_TBLOCK):
+        part = np.zeros((n_coef, C), dtype=np.float64)
+        for t in range(t0, min(t0 + DETREND_TBLOCK, T)):
+            part += pmodel[t][:, None] * x[t].astype(np.float64)[None, :]
+        coef += part
     resid = np.empty_like(x)
     for t in range(T):
         trend = np.zeros(C, dtype=np.float64)
@@ -189,8 +198,11 @@ def detrend_anomaly(x: np.ndarray, model: np.ndarray, pmodel: np.ndarray, force_
         resid[t] = x[t] - trend.astype(np.float32)
     if force_zero_mean:
         mean = np.zeros(C, dtype=np.float64)
-        for t in range(T):
-            mean += resid[t].astype(np.float64)
+        for t0 in range(0, T, DETREND_TBLOCK):
+            part = np.zeros(C, dtype=np.float64)
+            for t in range(t0, min(t0 + DETREND_TBLOCK, T)):
+                part += resid[t].astype(np.float64)
+            mean += part
         mean = (mean / np.float64(T)).astype(np.float32)
         resid = (resid - mean[None, :]).astype(np.float32)
     return resid
