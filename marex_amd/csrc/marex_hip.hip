@@ -1033,6 +1033,10 @@ __device__ __forceinline__ unsigned ordered_key(float v) {
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+__device__ __forceinline__ unsigned hist_get(const unsigned* h, int b, int lane) {
+    return (h[(b >> 1) * 64 + lane] >> ((b & 1) * 16)) & 0xFFFFu;  // [dword][64 lanes], two uint16 counters per dword
+}
+
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -2460,6 +2464,229 @@ k_global_approx(const float* __restrict__ anom, long T, long C, const double* __
     thr[c] = r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Global thresholds, second generation (series of at most 65 535 steps): one wave = 64 cells, per-lane histograms
+// with uint16 counters packed two per dword and stored lane-interleaved ([dword][lane]: every LDS access of a wave is
+// conflict-free whatever bins the lanes hit), 16 coalesced row loads in flight.  Same arithmetic as k_global_approx /
+// k_global_exact, which remain the fallback for longer series.
+// ------------------------------------------------------------------------------------------------
+#define G2_LANES 64
+#define G2_BATCH 16
+
+__global__ void __launch_bounds__(G2_LANES)
+k_global_approx16(const float* __restrict__ anom, long T, long C, const double* __restrict__ edges,
+                  const double* __restrict__ centres, int nb, double q, double lower_bound, double upper_bound,
+                  double* __restrict__ thr, marex_thr_stats* __restrict__ stats, double* __restrict__ minmax) {
+    extern __shared__ unsigned g2[];
+    const int nbw = (nb + 1) >> 1;
+    unsigned* hist = g2;                                               // [nbw][64]
+    double* led = reinterpret_cast<double*>(g2 + (size_t)nbw * G2_LANES);  // [nb + 1] edges
+    const int lane = threadIdx.x;
+    for (int i = lane; i <= nb; i += G2_LANES) led[i] = edges[i];
+    for (int d = 0; d < nbw; ++d) hist[d * G2_LANES + lane] = 0u;
+    __syncthreads();
+    const long c = (long)blockIdx.x * G2_LANES + lane;
+    if (c >= C) return;  // single wave, no barrier below
+    auto H = [&](int b) { return (double)((hist[(b >> 1) * G2_LANES + lane] >> ((b & 1) * 16)) & 0xFFFFu); };
+    const double e1 = led[1], elast = led[nb];
+    const double inv_width = (double)(nb - 1) / (elast - e1);
+    bool any_nan = false;
+    auto count = [&](float vf) {
+        if (!(vf == vf)) {
+            any_nan = true;
+            return;
+        }
+        const double v = (double)vf;
+        int k;
+        if (v > elast) return;              // beyond the last edge: not counted
+        if (v == elast) k = nb - 1;         // right edge belongs to the last bin (np.histogram rule)
+        else if (v < e1) k = 0;
+        else {
+            k = 1 + (int)((v - e1) * inv_width);
+            k = k < 1 ? 1 : (k > nb - 1 ? nb - 1 : k);
+            while (k > 1 && v < led[k]) --k;
+            while (k < nb - 1 && v >= led[k + 1]) ++k;
+        }
+        hist[(k >> 1) * G2_LANES + lane] += 1u << ((k & 1) * 16);
+    };
+    long t = 0;
+    for (; t + G2_BATCH <= T; t += G2_BATCH) {
+        float v[G2_BATCH];
+#pragma unroll
+        for (int u = 0; u < G2_BATCH; ++u) v[u] = anom[(size_t)(t + u) * C + c];
+#pragma unroll
+        for (int u = 0; u < G2_BATCH; ++u) count(v[u]);
+    }
+    for (; t < T; ++t) count(anom[(size_t)t * C + c]);
+
+    double hsum = 0.0;
+    for (int b = 0; b < nb; ++b) hsum += H(b);
+    hsum += 1e-10;
+    const double eps = 1e-10;
+    int iu = 0;
+    {
+        double cdf = 0.0;
+        bool found = false;
+        for (int b = 0; b < nb; ++b) {
+            cdf += H(b) / hsum;
+            if (!found && cdf >= q - eps) {
+                iu = b;
+                found = true;
+            }
+        }
+    }
+    const int ib = (iu - 1 > 0) ? iu - 1 : 0;
+    double cdf_t = 0.0;
+    {
+        double cdf = 0.0;
+        for (int b = 0; b <= ib; ++b) cdf += H(b) / hsum;
+        cdf_t = cdf;
+    }
+    int il = 0;
+    {
+        double cdf = 0.0;
+        bool found = false;
+        for (int b = 0; b < nb; ++b) {
+            cdf += H(b) / hsum;
+            if (!found && cdf > cdf_t) {
+                il = b;
+                found = true;
+            }
+        }
+    }
+    if (il > nb - 2) il = nb - 2;
+    if (iu < 1) iu = 1;
+    if (iu > nb - 1) iu = nb - 1;
+    double cl = 0.0, cu = 0.0;
+    {
+        double cdf = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            cdf += H(b) / hsum;
+            if (b == il) cl = cdf;
+            if (b == iu) cu = cdf;
+        }
+    }
+    const double bl = centres[il], bu = centres[iu];
+    const double denom = cu - cl;
+    const bool exact = fabs(cl - q) < eps, zero = fabs(denom) <= eps;
+    const double frac = (q - cl) / (fabs(denom) > eps ? denom : 1.0);
+    double r = bl + frac * (bu - bl);
+    if (exact) r = bl;
+    if (zero && !exact) r = (bl + bu) / 2;
+    if (any_nan) r = __longlong_as_double(0x7FF8000000000000ll);
+    if (r == r) {
+        unsigned long long* pmin = (unsigned long long*)&minmax[0];
+        unsigned long long* pmax = (unsigned long long*)&minmax[1];
+        unsigned long long old = *pmin;
+        while (r < __longlong_as_double((long long)old)) {
+            const unsigned long long seen = atomicCAS(pmin, old, (unsigned long long)__double_as_longlong(r));
+            if (seen == old) break;
+            old = seen;
+        }
+        old = *pmax;
+        while (r > __longlong_as_double((long long)old)) {
+            const unsigned long long seen = atomicCAS(pmax, old, (unsigned long long)__double_as_longlong(r));
+            if (seen == old) break;
+            old = seen;
+        }
+        if (r > upper_bound) atomicAdd(&stats->n_too_high, 1u);
+        if (r < lower_bound) {
+            atomicAdd(&stats->n_too_low, 1u);
+            r = lower_bound;
+        }
+    }
+    thr[c] = r;
+}
+
+// np.nanquantile(x, q), "linear": values at the ascending ranks lo = floor((m-1) q) and lo + 1 among the m non-NaN
+// samples.  Four 8-bit radix passes over an order-preserving key find rank lo (the first pass also counts m); the
+// descent knows how many samples are <= that value, so rank lo + 1 is either the same value (ties) or the smallest
+// larger sample, found by one more pass -- 5 passes over the series instead of 9.
+__global__ void __launch_bounds__(G2_LANES)
+k_global_exact16(const float* __restrict__ anom, long T, long C, double q, double* __restrict__ thr) {
+    extern __shared__ unsigned g2[];  // [128][64]: 256 uint16 counters per lane
+    const int lane = threadIdx.x;
+    const long c = (long)blockIdx.x * G2_LANES + lane;
+    if (c >= C) return;
+    auto H = [&](int b) { return (hist_get(g2, b, lane)); };
+    unsigned prefix = 0, pmask = 0;
+    long m = 0, rank = 0, lo = 0, hi = 0, below = 0;  // below = samples smaller than the current prefix bucket
+    double g = 0.0;
+    unsigned n_final = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int sh = 24 - 8 * pass;
+        for (int d = 0; d < 128; ++d) g2[d * G2_LANES + lane] = 0u;
+        auto count = [&](float v) {
+            if (!(v == v)) return;
+            const unsigned k = ordered_key(v);
+            if ((k & pmask) == prefix) {
+                const unsigned b = (k >> sh) & 255u;
+                g2[(b >> 1) * G2_LANES + lane] += 1u << ((b & 1u) * 16);
+            }
+        };
+        long t = 0;
+        for (; t + G2_BATCH <= T; t += G2_BATCH) {
+            float v[G2_BATCH];
+#pragma unroll
+            for (int u = 0; u < G2_BATCH; ++u) v[u] = anom[(size_t)(t + u) * C + c];
+#pragma unroll
+            for (int u = 0; u < G2_BATCH; ++u) count(v[u]);
+        }
+        for (; t < T; ++t) count(anom[(size_t)t * C + c]);
+        if (pass == 0) {
+            for (int b = 0; b < 256; ++b) m += H(b);
+            if (m == 0) {
+                thr[c] = __longlong_as_double(0x7FF8000000000000ll);
+                return;
+            }
+            const double virt = (double)(m - 1) * q;
+            lo = (long)floor(virt);
+            g = virt - (double)lo;
+            hi = lo + 1;
+            if (lo >= m - 1) {
+                lo = m - 1;
+                hi = m - 1;
+            }
+            rank = lo;
+        }
+        int b = 0;
+        for (; b < 255; ++b) {
+            const unsigned n = H(b);
+            if ((unsigned long long)rank < n) break;
+            rank -= n;
+            below += n;
+        }
+        n_final = H(b);
+        prefix |= (unsigned)b << sh;
+        pmask |= 255u << sh;
+    }
+    const float a = key_to_float(prefix);
+    float bv = a;
+    if (hi != lo && hi >= below + (long)n_final) {  // rank lo + 1 is not another copy of a: smallest larger sample
+        unsigned best = 0xFFFFFFFFu;
+        auto look = [&](float v) {
+            if (!(v == v)) return;
+            const unsigned k = ordered_key(v);
+            if (k > prefix && k < best) best = k;
+        };
+        long t = 0;
+        for (; t + G2_BATCH <= T; t += G2_BATCH) {
+            float v[G2_BATCH];
+#pragma unroll
+            for (int u = 0; u < G2_BATCH; ++u) v[u] = anom[(size_t)(t + u) * C + c];
+#pragma unroll
+            for (int u = 0; u < G2_BATCH; ++u) look(v[u]);
+        }
+        for (; t < T; ++t) look(anom[(size_t)t * C + c]);
+        bv = key_to_float(best);
+    }
+    const double ad = (double)a, bd = (double)bv;
+    const double dba = (double)(bv - a);  // float32 subtraction as in NumPy's _lerp
+    double r = ad + dba * g;
+    if (g >= 0.5) r = bd - dba * (1.0 - g);
+    thr[c] = r;
+}
+
 extern "C" int marex_global_threshold_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, double q,
                                           int exact, const double* edges, const double* centres, int nb,
                                           double lower_bound, double upper_bound, double* thr,
@@ -2469,7 +2696,12 @@ extern "C" int marex_global_threshold_f32(marex_ctx* ctx, const float* anom, int
     if (!(q >= 0.0 && q <= 1.0)) return fail(ctx, -1, "marex_global_threshold_f32: q must be in [0, 1]");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     LaunchTimer lt(ctx, MAREX_K_GLOBAL);
-    if (exact) {
+    const bool small_counts = T_out <= 65535 && env_int("MAREX_GLOBAL_V1", 0) == 0;  // uint16 counters suffice
+    if (exact && small_counts) {
+        const size_t lds = 128 * G2_LANES * 4;  // 32 KiB
+        hipLaunchKernelGGL(k_global_exact16, dim3((unsigned)((C + G2_LANES - 1) / G2_LANES)), dim3(G2_LANES), lds,
+                           ctx->stream, anom, (long)T_out, (long)C, q, thr);
+    } else if (exact) {
         const size_t lds = 256 * GX_LANES * 4;  // 64 KiB
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_global_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_global_exact, dim3((unsigned)((C + GX_LANES - 1) / GX_LANES)), dim3(GX_LANES), lds,
@@ -2477,6 +2709,16 @@ extern "C" int marex_global_threshold_f32(marex_ctx* ctx, const float* anom, int
     } else {
         if (!edges || !centres || !stats || !minmax || nb < 4 || nb > 600)
             return fail(ctx, -1, "marex_global_threshold_f32: approximate method needs edges, centres, stats, minmax and 4 <= nb <= 600");
+        if (small_counts) {
+            const size_t lds2 = (size_t)((nb + 1) / 2) * G2_LANES * 4 + (size_t)(nb + 1) * 8;  // <= 82 KiB for nb <= 600
+            if (lds2 > 48 * 1024)
+                HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_global_approx16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            hipLaunchKernelGGL(k_global_approx16, dim3((unsigned)((C + G2_LANES - 1) / G2_LANES)), dim3(G2_LANES), lds2,
+                               ctx->stream, anom, (long)T_out, (long)C, edges, centres, nb, q, lower_bound, upper_bound, thr,
+                               stats, minmax);
+            HIP_TRY(ctx, hipGetLastError());
+            return 0;
+        }
         const size_t lds = (size_t)nb * GA_LANES * 4;  // <= 75 KiB for nb <= 600
         if (lds > 48 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_global_approx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

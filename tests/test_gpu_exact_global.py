@@ -88,3 +88,32 @@ def test_global_approx_threshold(hot, pct):
     # within the reference's own tolerance of np.percentile for smooth data (tests/test_detect_helpers.py:172-233)
     ocean = np.isfinite(anom[0]) & (np.arange(anom.shape[1]) != 7)
     assert np.abs(got[ocean] - np.percentile(anom[:, ocean], pct, axis=0)).max() < 0.02
+
+
+def test_global_threshold_fallback_kernels_agree(hot, monkeypatch):
+    """Series longer than 65 535 steps use the first-generation kernels (32-bit counters); force them on a short series."""
+    anom, cal = _anomalies(hot, "2002-01-01", 9 * 365 + 2, 5, 13)
+    a = torch.from_numpy(anom).to(hot.device)
+    new_e = hot.global_threshold(a, 95.0, "exact", None)["thr_f64"].cpu().numpy()
+    new_a = hot.global_threshold(a, 95.0, "approximate", binning.hobday_bins())["thr_f64"].cpu().numpy()
+    monkeypatch.setenv("MAREX_GLOBAL_V1", "1")
+    old_e = hot.global_threshold(a, 95.0, "exact", None)["thr_f64"].cpu().numpy()
+    old_a = hot.global_threshold(a, 95.0, "approximate", binning.hobday_bins())["thr_f64"].cpu().numpy()
+    assert np.array_equal(new_e, old_e, equal_nan=True) and np.array_equal(new_a, old_a, equal_nan=True)
+
+
+def test_global_exact_with_ties_infinities_and_tiny_series(hot):
+    rng = np.random.default_rng(5)
+    for T in (1, 2, 7, 40):
+        x = rng.normal(0, 1, (T, 70)).astype(np.float32)
+        x[:, 3] = np.round(x[:, 3])                 # ties
+        x[:, 4] = 1.5                               # all equal
+        if T > 2:
+            x[1, 5] = np.inf
+            x[2, 6] = -np.inf
+            x[0, 7] = np.nan
+        x[:, 8] = np.nan                            # all NaN -> NaN
+        for pct in (0.0, 50.0, 95.0, 100.0):
+            exp = orc.global_threshold_exact(x, pct)
+            got = hot.global_threshold(torch.from_numpy(x).to(hot.device), pct, "exact", None)["thr_f64"].cpu().numpy()
+            assert np.array_equal(got, exp, equal_nan=True), (T, pct)
