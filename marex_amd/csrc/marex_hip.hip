@@ -2751,16 +2751,56 @@ k_mask_ge_const(const float* __restrict__ anom, const double* __restrict__ thr, 
     }
 }
 
+// four cells per lane: 16-byte anomaly loads, 4-byte mask stores, four rows in flight
+__global__ void __launch_bounds__(256)
+k_mask_ge_const4(const float* __restrict__ anom, const double* __restrict__ thr, long T, long C, int rows_per_block,
+                 unsigned char* __restrict__ out, unsigned long long* __restrict__ n_true) {
+    const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    unsigned cnt = 0;
+    if (c < C) {
+        const double t0d = thr[c], t1d = thr[c + 1], t2d = thr[c + 2], t3d = thr[c + 3];
+        const long t0 = (long)blockIdx.y * rows_per_block;
+        const long t1 = t0 + rows_per_block < T ? t0 + rows_per_block : T;
+        auto one = [&](long t, float4 a) {
+            uchar4 m;
+            m.x = (double)a.x >= t0d;
+            m.y = (double)a.y >= t1d;
+            m.z = (double)a.z >= t2d;
+            m.w = (double)a.w >= t3d;
+            cnt += m.x + m.y + m.z + m.w;
+            *reinterpret_cast<uchar4*>(out + (size_t)t * C + c) = m;
+        };
+        long t = t0;
+        for (; t + 4 <= t1; t += 4) {
+            float4 a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(anom + (size_t)(t + u) * C + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) one(t + u, a[u]);
+        }
+        for (; t < t1; ++t) one(t, *reinterpret_cast<const float4*>(anom + (size_t)t * C + c));
+    }
+    if (n_true) {
+        for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s, 64);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(n_true, (unsigned long long)cnt);
+    }
+}
+
 extern "C" int marex_mask_ge_const_f32(marex_ctx* ctx, const float* anom, const double* thr, int64_t T_out, int64_t C,
                                        uint8_t* extreme, unsigned long long* n_true) {
     if (!ctx) return -1;
     if (!anom || !thr || !extreme || T_out <= 0 || C <= 0) return fail(ctx, -1, "marex_mask_ge_const_f32: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int rows = 64;
-    dim3 grid((unsigned)((C + 255) / 256), (unsigned)((T_out + rows - 1) / rows));
     {
         LaunchTimer lt(ctx, MAREX_K_MASK);
-        hipLaunchKernelGGL(k_mask_ge_const, grid, dim3(256), 0, ctx->stream, anom, thr, (long)T_out, (long)C, rows, extreme, n_true);
+        if ((C & 3) == 0) {
+            dim3 grid((unsigned)((C / 4 + 255) / 256), (unsigned)((T_out + rows - 1) / rows));
+            hipLaunchKernelGGL(k_mask_ge_const4, grid, dim3(256), 0, ctx->stream, anom, thr, (long)T_out, (long)C, rows, extreme, n_true);
+        } else {
+            dim3 grid((unsigned)((C + 255) / 256), (unsigned)((T_out + rows - 1) / rows));
+            hipLaunchKernelGGL(k_mask_ge_const, grid, dim3(256), 0, ctx->stream, anom, thr, (long)T_out, (long)C, rows, extreme, n_true);
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
