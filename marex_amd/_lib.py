@@ -13,7 +13,7 @@ from typing import Optional
 from .exceptions import DependencyError, ProcessingError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmarex_hip.so")
+LIB_PATH = os.environ.get("MAREX_LIB_PATH") or os.path.join(_HERE, "csrc", "libmarex_hip.so")  # override: experiments
 
 _p = C.c_void_p
 _i32 = C.c_int

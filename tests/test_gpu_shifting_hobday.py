@@ -140,15 +140,31 @@ def test_threshold_edge_quantiles_and_windows(hot):
 def test_shifting_chunk_variants(hot, monkeypatch):
     """Every dayofyear-chunk width / history placement (registers or LDS ring) of the anomaly kernel gives
     identical bits, for W inside both ring capacities (8 and 16)."""
-    for ring, D in (("0", "1"), ("0", "4"), ("1", "2"), ("1", "4"), ("1", "8")):
+    # MAREX_SHIFT_D / MAREX_SHIFT_FAST=0 route everything through the general kernel k_shifting
+    for ring, D in (("0", "1"), ("0", "4"), ("1", "2"), ("1", "4"), ("1", "8"), ("1", "fast-off")):
         monkeypatch.setenv("MAREX_SHIFT_RING", ring)
-        monkeypatch.setenv("MAREX_SHIFT_D", D)
+        if D == "fast-off":
+            monkeypatch.delenv("MAREX_SHIFT_D", raising=False)
+            monkeypatch.setenv("MAREX_SHIFT_FAST", "0")
+        else:
+            monkeypatch.setenv("MAREX_SHIFT_D", D)
         r = run_case(hot, "2003-01-01", 9 * 365 + 2, 7, 21, 4, 21, 11, 5)
         check_all(*r)
         r = run_case(hot, "1990-06-01", 20 * 365 + 5, 5, 9, 13, 21, 11, 3)
         check_all(*r)
-    monkeypatch.delenv("MAREX_SHIFT_D")
+    monkeypatch.delenv("MAREX_SHIFT_D", raising=False)
+    monkeypatch.delenv("MAREX_SHIFT_FAST", raising=False)
     monkeypatch.delenv("MAREX_SHIFT_RING")
+
+
+def test_fast_anomaly_kernel_instances_and_general_fallbacks(hot):
+    """Every instantiated W of k_shift_fast, a W without an instance (general kernel), even W (real division),
+    series starting mid-chunk and ending mid-year (edge years, partial chunks)."""
+    for W, start, periods in ((3, "2004-01-01", 8 * 365 + 2), (6, "2001-03-17", 11 * 365 + 100), (7, "2000-01-01", 12 * 365 + 3),
+                              (10, "1996-01-01", 16 * 365 + 4), (13, "1990-06-01", 20 * 365 + 5), (8, "1999-01-01", 13 * 365 + 3),
+                              (16, "1990-01-01", 21 * 365 + 5)):
+        r = run_case(hot, start, periods, 5, 9, W, 21, 11, 3)
+        check_all(*r)
 
 
 def test_long_buckets_pick_the_big_tile(hot):
