@@ -1856,7 +1856,8 @@ __global__ void __launch_bounds__(256)
 k_mask_ge(const float* __restrict__ anom, const float* __restrict__ thr, const int* __restrict__ doy_start,
           const int* __restrict__ doy_rows, long C, long c0, long c1, unsigned char* __restrict__ out,
           unsigned long long* __restrict__ n_true) {
-    const int dA = (int)blockIdx.y * NDOY / MASK_DOY_CHUNKS, dB = ((int)blockIdx.y + 1) * NDOY / MASK_DOY_CHUNKS;
+    const int nchunk = (int)gridDim.y;  // the dayofyear axis is cut into gridDim.y pieces
+    const int dA = (int)blockIdx.y * NDOY / nchunk, dB = ((int)blockIdx.y + 1) * NDOY / nchunk;
     const long c = c0 + ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
     unsigned cnt = 0;
     if (c < c1) {
@@ -1871,7 +1872,11 @@ k_mask_ge(const float* __restrict__ anom, const float* __restrict__ thr, const i
 #pragma unroll
                     for (int u = 0; u < 4; ++u) off[u] = (size_t)doy_rows[r + u] * C + c;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(anom + off[u]);
+                    for (int u = 0; u < 4; ++u) {
+                        typedef float f4_t __attribute__((ext_vector_type(4)));
+                        const f4_t q4 = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(anom + off[u]));
+                        a[u] = make_float4(q4.x, q4.y, q4.z, q4.w);
+                    }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         uchar4 m;
@@ -1880,7 +1885,8 @@ k_mask_ge(const float* __restrict__ anom, const float* __restrict__ thr, const i
                         m.z = a[u].z >= th.z;
                         m.w = a[u].w >= th.w;
                         cnt += m.x + m.y + m.z + m.w;
-                        *reinterpret_cast<uchar4*>(out + off[u]) = m;
+                        __builtin_nontemporal_store((unsigned)m.x | ((unsigned)m.y << 8) | ((unsigned)m.z << 16) | ((unsigned)m.w << 24),
+                                                    reinterpret_cast<unsigned*>(out + off[u]));
                     }
                 }
                 for (; r < r1; ++r) {
@@ -1924,7 +1930,11 @@ extern "C" int marex_mask_ge_doy_f32(marex_ctx* ctx, const float* anom, const fl
     {
         LaunchTimer lt(ctx, MAREX_K_MASK);
         if (vec) {
-            dim3 grid((unsigned)((nc / 4 + 255) / 256), MASK_DOY_CHUNKS);
+            // enough workgroups to fill the chip whatever the number of cells (a 100-yr latitude band has 133 cell blocks)
+            const unsigned ncb4 = (unsigned)((nc / 4 + 255) / 256);
+            unsigned chunks = (4096 + ncb4 - 1) / ncb4;
+            chunks = chunks < MASK_DOY_CHUNKS ? MASK_DOY_CHUNKS : (chunks > 61 ? 61 : chunks);
+            dim3 grid(ncb4, chunks);
             hipLaunchKernelGGL(k_mask_ge<4>, grid, dim3(256), 0, ctx->stream, anom, thr_doy_major, doy_start, doy_rows,
                                (long)C, (long)c0, (long)c1, extreme, n_true);
         } else {
