@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <type_traits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -756,16 +757,20 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     }
     __syncthreads();
 
-    v2f rA[W], rB[W];  // history of dayofyears (0,1) and (2,3): [0] = year y-W ... [W-1] = year y-1
+    // History of dayofyears (0,1) and (2,3) as register lines.  The year loop is unrolled by two: the first year of a
+    // pair reads entries [0, W) and appends at [W], the second reads [1, W] and appends at [W+1], then the line moves
+    // down by two -- W moves per two years instead of 2 (W - 1).
+    v2f rA[W + 2], rB[W + 2];
 #pragma unroll
-    for (int j = 0; j < W; ++j) rA[j] = rB[j] = splat2(qnan);
+    for (int j = 0; j < W + 2; ++j) rA[j] = rB[j] = splat2(qnan);
     int n_invalid = 0;
 
     const int4* pp = year_plan + d0;
     const bool tail = d0 + 3 >= NDOY;  // last chunk: dayofyears 365, 366 and two that do not exist
     const int4 absent = make_int4(-1, -1, -1, 0);
     int4 n0 = pp[0], n1 = pp[1], n2 = tail ? absent : pp[2], n3 = tail ? absent : pp[3];
-    for (int y = 0; y < n_cal; ++y) {
+    auto one_year = [&](int y, auto Jc) {
+        constexpr int J = decltype(Jc)::value;
         const int4 p0 = n0, p1 = n1, p2 = n2, p3 = n3;
         const int tb = tb_next;
         float nx[9];
@@ -842,8 +847,8 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                 v2f sA = splat2(0.f), sB = splat2(0.f);
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
-                    sA = sA + rA[j];
-                    sB = sB + rB[j];
+                    sA = sA + rA[J + j];
+                    sB = sB + rB[J + j];
                 }
                 // the reciprocal form is exact for odd W and powers of two only (even W have halfway cases among
                 // subnormal quotients that it misrounds: oracle/proofs/div_by_const.c); other W divide for real
@@ -866,7 +871,7 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                     int n[4] = {0, 0, 0, 0};
 #pragma unroll
                     for (int j = 0; j < W; ++j) {
-                        const float v[4] = {rA[j].x, rA[j].y, rB[j].x, rB[j].y};
+                        const float v[4] = {rA[J + j].x, rA[J + j].y, rB[J + j].x, rB[J + j].y};
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             if (v[i] == v[i]) {
@@ -913,16 +918,19 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                 }
             }
         }
-        // year y replaces year y-W
-#pragma unroll
-        for (int j = 0; j + 1 < W; ++j) {
-            rA[j] = rA[j + 1];
-            rB[j] = rB[j + 1];
-        }
-        rA[W - 1] = smA;
-        rB[W - 1] = smB;
+        rA[J + W] = smA;  // year y joins the history
+        rB[J + W] = smB;
         if (stage_next) stage_store((y + 1) & 1, nx);
         __syncthreads();
+    };
+    for (int y = 0; y < n_cal; y += 2) {
+        one_year(y, std::integral_constant<int, 0>{});
+        if (y + 1 < n_cal) one_year(y + 1, std::integral_constant<int, 1>{});
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            rA[j] = rA[j + 2];
+            rB[j] = rB[j + 2];
+        }
     }
     if (invalid_count && active && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
 }
