@@ -43,6 +43,13 @@ C4  bins (detect.py:2603-2631): ``np.digitize(anom, edges) - 1`` with the float3
 C5  counts, pooling and the count-interpolated quantile are integer / float64
     exactly as in detect.py:2494-2559, 2652-2668, 2704-2732.
 C6  mask (detect.py:2004): ``anom >= thr`` (False when either side is NaN).
+C7  detrend (detect.py:2143-2224): float64 reductions over time as partial sums over blocks of
+    ``DETREND_TBLOCK`` = 1024 consecutive timesteps (ascending t, from 0.0) combined in ascending
+    block order (from 0.0); trend = float64 sum over coefficients in ascending k, rounded to float32
+    once; time mean rounded to float32 once.  Against the reference (BLAS order unspecified) this
+    stage is tolerance-only.
+C8  std_normalise (detect.py:2257-2278): see ``std_normalise`` -- float64 two-pass population std
+    per dayofyear, float32 squares, float64 30-term wrapped window mean, float32 sqrt and division.
 """
 
 from __future__ import annotations
