@@ -1,0 +1,351 @@
+// marex_anomalies.hip -- fixed baseline, digitize, detrend, std_normalise
+#include "marex_common.hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// K_F: fixed-baseline anomaly (detect.py:2299-2397).  Work item = (256 cells, one dayofyear): the
+// float32 nanmean of all timesteps of that dayofyear (optionally only reference-period years) in
+// ascending time, then anom = x - clim for the same rows (second read comes from L2).  Also emits the
+// dayofyear-sorted bins, the t=0 mask and the validation counts like the shifting-baseline kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_fixed_baseline(const float* __restrict__ x, long T, long C, const int* __restrict__ doy_start,
+                 const int* __restrict__ doy_rows, const unsigned char* __restrict__ use_row,
+                 const float* __restrict__ edges, int nb, float* __restrict__ out,
+                 unsigned short* __restrict__ bins, unsigned char* __restrict__ mask,
+                 int* __restrict__ invalid_count) {
+    extern __shared__ float e[];
+    const int d = blockIdx.y;
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool do_bins = bins != nullptr;
+    if (do_bins) {
+        for (int i = threadIdx.x; i <= nb; i += 256) e[i] = edges[i];
+        __syncthreads();
+    }
+    if (c >= C) return;
+    const float inv_width = do_bins ? (float)(nb - 1) / (e[nb] - e[1]) : 0.f;
+    if (d == 0 && mask) mask[c] = finite_f(x[c]) ? 1 : 0;
+    const int r0 = doy_start[d], r1 = doy_start[d + 1];
+    float acc = 0.f;
+    int n = 0, n_invalid = 0;
+    for (int r = r0; r < r1; ++r) {
+        const int t = doy_rows[r];
+        const float v = x[(size_t)t * C + c];
+        if (!finite_f(v)) ++n_invalid;
+        if ((!use_row || use_row[t]) && v == v) {
+            acc += v;
+            ++n;
+        }
+    }
+    const float clim = acc / (float)n;  // n == 0 -> NaN
+    for (int r = r0; r < r1; ++r) {
+        const int t = doy_rows[r];
+        const float a = x[(size_t)t * C + c] - clim;
+        out[(size_t)t * C + c] = a;
+        if (do_bins) bins[bins_index(r, c, T)] = (unsigned short)digitize_bin(a, e, nb, inv_width);
+    }
+    if (invalid_count && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
+}
+
+extern "C" int marex_fixed_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
+                                        const int32_t* doy_start, const int32_t* doy_rows,
+                                        const uint8_t* use_row, const float* edges, int nb, float* out,
+                                        uint16_t* bins, uint8_t* mask, int32_t* invalid_count) {
+    if (!ctx) return -1;
+    if (!x || !doy_start || !doy_rows || !out || T <= 0 || C <= 0)
+        return fail(ctx, -1, "marex_fixed_baseline_f32: null pointer or empty shape");
+    if (bins && (!edges || nb < 4 || nb > 36000)) return fail(ctx, -1, "marex_fixed_baseline_f32: binning needs edges and 4 <= nb <= 36000");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((C + 255) / 256), NDOY);
+    const size_t lds = bins ? ((size_t)nb + 1) * sizeof(float) : 0;
+    if (lds > 48 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_fixed_baseline, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        LaunchTimer lt(ctx, MAREX_K_FIXED);
+        hipLaunchKernelGGL(k_fixed_baseline, grid, dim3(256), lds, ctx->stream, x, (long)T, (long)C, doy_start, doy_rows,
+                           use_row, edges, nb, out, bins, mask, invalid_count);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone binning of an anomaly field into the dayofyear-sorted bin matrix (detect.py:2622-2631)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_digitize(const float* __restrict__ anom, long T, long C, const int* __restrict__ rowb_index,
+           const float* __restrict__ edges, int nb, int rows_per_block, long T_out, unsigned short* __restrict__ bins) {
+    extern __shared__ float e[];
+    for (int i = threadIdx.x; i <= nb; i += 256) e[i] = edges[i];
+    __syncthreads();
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float inv_width = (float)(nb - 1) / (e[nb] - e[1]);
+    const long t0 = (long)blockIdx.y * rows_per_block;
+    const long t1 = t0 + rows_per_block < T ? t0 + rows_per_block : T;
+    for (long t = t0; t < t1; ++t) {
+        const int rb = rowb_index[t];
+        if (rb >= 0) bins[bins_index(rb, c, T_out)] = (unsigned short)digitize_bin(anom[(size_t)t * C + c], e, nb, inv_width);
+    }
+}
+
+extern "C" int marex_digitize_f32(marex_ctx* ctx, const float* anom, int64_t T, int64_t C, const int32_t* rowb_index,
+                                  const float* edges, int nb, int64_t T_out, uint16_t* bins) {
+    if (!ctx) return -1;
+    if (!anom || !rowb_index || !edges || !bins || T <= 0 || C <= 0 || nb < 4 || nb > 36000 || T_out <= 0)
+        return fail(ctx, -1, "marex_digitize_f32: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rows = 32;
+    dim3 grid((unsigned)((C + 255) / 256), (unsigned)((T + rows - 1) / rows));
+    const size_t lds = ((size_t)nb + 1) * sizeof(float);
+    if (lds > 48 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_digitize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        LaunchTimer lt(ctx, MAREX_K_FIXED);
+        hipLaunchKernelGGL(k_digitize, grid, dim3(256), lds, ctx->stream, anom, (long)T, (long)C, rowb_index, edges, nb,
+                           rows, (long)T_out, bins);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_D: polynomial / harmonic detrend (detect.py:2143-2224).  One lane per cell streams its series:
+//   pass 1  coef[k] = sum_t pmodel[t][k] * x[t]      (float64, ascending t, separately rounded mul/add)
+//   pass 2  resid[t] = x[t] - fl32( sum_k model[k][t] * coef[k] )   and the float64 sum of resid
+//   pass 3  (force_zero_mean) resid[t] -= fl32( sum / T )
+// n_coef <= 8 (1 + polynomial orders + 4 harmonics): 4 flop per byte, far below any MFMA use.
+// The model tables are tiny ([T, n_coef] float64) and read through the scalar cache (uniform address).
+// ------------------------------------------------------------------------------------------------
+#define DETREND_MAXC 12
+#define DETREND_TBLOCK 1024  // timesteps per partial sum (arithmetic contract, oracle.DETREND_TBLOCK)
+
+// Reductions over time are split into blocks of DETREND_TBLOCK timesteps so that the grid is (cell blocks x time
+// blocks) instead of one thread walking 36 500 rows: float64 partial sums per block in ascending t, combined in
+// ascending block order -- a fixed order, mirrored by the oracle.
+__global__ void __launch_bounds__(256)
+k_detrend_partial(const float* __restrict__ x, long T, long C, const double* __restrict__ pmodel /*[T][n]*/, int n_coef,
+                  double* __restrict__ partial /*[ntb][n][C]*/, int* __restrict__ invalid_count) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long t0 = (long)blockIdx.y * DETREND_TBLOCK;
+    const long t1 = t0 + DETREND_TBLOCK < T ? t0 + DETREND_TBLOCK : T;
+    double acc[DETREND_MAXC];
+#pragma unroll
+    for (int k = 0; k < DETREND_MAXC; ++k) acc[k] = 0.0;
+    int n_invalid = 0;
+#pragma unroll 4
+    for (long t = t0; t < t1; ++t) {
+        const float v = x[(size_t)t * C + c];
+        n_invalid += finite_f(v) ? 0 : 1;
+        const double vd = (double)v;
+        const double* pm = pmodel + (size_t)t * n_coef;
+#pragma unroll
+        for (int k = 0; k < DETREND_MAXC; ++k)
+            if (k < n_coef) acc[k] += pm[k] * vd;
+    }
+    for (int k = 0; k < n_coef; ++k) partial[((size_t)blockIdx.y * n_coef + k) * C + c] = acc[k];
+    if (invalid_count && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
+}
+
+__global__ void __launch_bounds__(256)
+k_detrend_combine(const float* __restrict__ x, long C, int ntb, int n_coef, const double* __restrict__ partial,
+                  double* __restrict__ coef /*[n][C]*/, unsigned char* __restrict__ mask) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    for (int k = 0; k < n_coef; ++k) {
+        double s = 0.0;
+        for (int b = 0; b < ntb; ++b) s += partial[((size_t)b * n_coef + k) * C + c];
+        coef[(size_t)k * C + c] = s;
+    }
+    if (mask) mask[c] = finite_f(x[c]) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+k_detrend_resid(const float* __restrict__ x, long T, long C, const double* __restrict__ model_t /*[T][n]*/, int n_coef,
+                const double* __restrict__ coef, float* __restrict__ out, double* __restrict__ psum /*[ntb][C]*/) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long t0 = (long)blockIdx.y * DETREND_TBLOCK;
+    const long t1 = t0 + DETREND_TBLOCK < T ? t0 + DETREND_TBLOCK : T;
+    double cf[DETREND_MAXC];
+#pragma unroll
+    for (int k = 0; k < DETREND_MAXC; ++k) cf[k] = k < n_coef ? coef[(size_t)k * C + c] : 0.0;
+    double sum = 0.0;
+#pragma unroll 4
+    for (long t = t0; t < t1; ++t) {
+        const double* mt = model_t + (size_t)t * n_coef;
+        double trend = 0.0;
+#pragma unroll
+        for (int k = 0; k < DETREND_MAXC; ++k)
+            if (k < n_coef) trend += mt[k] * cf[k];
+        const float r = x[(size_t)t * C + c] - (float)trend;
+        out[(size_t)t * C + c] = r;
+        sum += (double)r;
+    }
+    psum[(size_t)blockIdx.y * C + c] = sum;
+}
+
+__global__ void __launch_bounds__(256)
+k_detrend_mean(long T, long C, int ntb, const double* __restrict__ psum, float* __restrict__ mean) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < ntb; ++b) s += psum[(size_t)b * C + c];
+    mean[c] = (float)(s / (double)T);
+}
+
+__global__ void __launch_bounds__(256)
+k_detrend_sub(long T, long C, const float* __restrict__ mean, float* __restrict__ out) {
+    const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= C) return;
+    const long t0 = (long)blockIdx.y * 64;
+    const long t1 = t0 + 64 < T ? t0 + 64 : T;
+    if (c + 4 <= C && (C & 3) == 0) {
+        const float4 m = *reinterpret_cast<const float4*>(mean + c);
+        for (long t = t0; t < t1; ++t) {
+            float4* p = reinterpret_cast<float4*>(out + (size_t)t * C + c);
+            float4 v = *p;
+            v.x -= m.x;
+            v.y -= m.y;
+            v.z -= m.z;
+            v.w -= m.w;
+            *p = v;
+        }
+    } else {
+        for (long t = t0; t < t1; ++t)
+            for (long cc = c; cc < C && cc < c + 4; ++cc) out[(size_t)t * C + cc] -= mean[cc];
+    }
+}
+
+extern "C" int marex_detrend_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
+                                 const double* model_t, int n_coef, int force_zero_mean, float* out, uint8_t* mask,
+                                 int32_t* invalid_count) {
+    if (!ctx) return -1;
+    if (!x || !pmodel || !model_t || !out || T <= 0 || C <= 0) return fail(ctx, -1, "marex_detrend_f32: null pointer or empty shape");
+    if (n_coef < 1 || n_coef > DETREND_MAXC) return fail(ctx, -4, "marex_detrend_f32: n_coef must be in 1..%d", DETREND_MAXC);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int ntb = (int)((T + DETREND_TBLOCK - 1) / DETREND_TBLOCK);
+    // scratch: partial [ntb][n][C] f64 (reused as psum [ntb][C]) + coef [n][C] f64 + mean [C] f32
+    const size_t need = ((size_t)ntb * n_coef + n_coef + 1) * (size_t)C * sizeof(double);
+    if (need > ctx->detrend_scratch_bytes) {
+        if (ctx->detrend_scratch) HIP_TRY(ctx, hipFree(ctx->detrend_scratch));
+        ctx->detrend_scratch = nullptr;
+        ctx->detrend_scratch_bytes = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->detrend_scratch, need));
+        ctx->detrend_scratch_bytes = need;
+    }
+    double* partial = reinterpret_cast<double*>(ctx->detrend_scratch);
+    double* coef = partial + (size_t)ntb * n_coef * C;
+    float* mean = reinterpret_cast<float*>(coef + (size_t)n_coef * C);
+    if (invalid_count) HIP_TRY(ctx, hipMemsetAsync(invalid_count, 0, (size_t)C * sizeof(int), ctx->stream));
+    const unsigned ncb = (unsigned)((C + 255) / 256);
+    {
+        LaunchTimer lt(ctx, MAREX_K_DETREND);
+        hipLaunchKernelGGL(k_detrend_partial, dim3(ncb, ntb), dim3(256), 0, ctx->stream, x, (long)T, (long)C, pmodel, n_coef,
+                           partial, invalid_count);
+        hipLaunchKernelGGL(k_detrend_combine, dim3(ncb), dim3(256), 0, ctx->stream, x, (long)C, ntb, n_coef, partial, coef,
+                           mask);
+        hipLaunchKernelGGL(k_detrend_resid, dim3(ncb, ntb), dim3(256), 0, ctx->stream, x, (long)T, (long)C, model_t, n_coef,
+                           coef, out, partial);
+        if (force_zero_mean) {
+            hipLaunchKernelGGL(k_detrend_mean, dim3(ncb), dim3(256), 0, ctx->stream, (long)T, (long)C, ntb, partial, mean);
+            hipLaunchKernelGGL(k_detrend_sub, dim3((unsigned)((C / 4 + 256) / 256), (unsigned)((T + 63) / 64)), dim3(256), 0,
+                               ctx->stream, (long)T, (long)C, mean, out);
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// std_normalise (detect.py:2257-2278): day-of-year standard deviation, wrapped rolling RMS, division
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_doy_std(const float* __restrict__ anom, const int* __restrict__ doy_start, const int* __restrict__ doy_rows, long C,
+          float* __restrict__ std_day) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    const int d = blockIdx.y;
+    if (c >= C) return;
+    const int r0 = doy_start[d], r1 = doy_start[d + 1];
+    float res = nan_f();
+    if (r1 > r0) {
+        double sum = 0.0;
+        for (int r = r0; r < r1; ++r) sum += (double)anom[(size_t)doy_rows[r] * C + c];
+        const double mean = sum / (double)(r1 - r0);
+        double ss = 0.0;
+        for (int r = r0; r < r1; ++r) {  // second pass over the same few rows (L2 resident)
+            const double dv = (double)anom[(size_t)doy_rows[r] * C + c] - mean;
+            ss += dv * dv;
+        }
+        res = (float)sqrt(ss / (double)(r1 - r0));
+    }
+    std_day[(size_t)d * C + c] = res;
+}
+
+__global__ void __launch_bounds__(256)
+k_std_rolling(const float* __restrict__ std_day, long C, int window, float* __restrict__ std_roll) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    const int d = blockIdx.y;
+    if (c >= C) return;
+    const int lo = window / 2;
+    double acc = 0.0;
+    for (int k = 0; k < window; ++k) {
+        int dd = (d - lo + k) % NDOY;
+        if (dd < 0) dd += NDOY;
+        const float sd = std_day[(size_t)dd * C + c];
+        const float sq = sd * sd;
+        acc += (double)sq;
+    }
+    const float m = (float)(acc / (double)window);
+    std_roll[(size_t)d * C + c] = sqrtf(m);
+}
+
+__global__ void __launch_bounds__(256)
+k_div_doy(const float* __restrict__ anom, const float* __restrict__ std_roll, const int* __restrict__ doy_start,
+          const int* __restrict__ doy_rows, long C, float* __restrict__ out) {
+    const int dA = (int)blockIdx.y * NDOY / MASK_DOY_CHUNKS, dB = ((int)blockIdx.y + 1) * NDOY / MASK_DOY_CHUNKS;
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    for (int d = dA; d < dB; ++d) {
+        const float sd = std_roll[(size_t)d * C + c];
+        const float safe = sd > 1e-10f ? sd : nan_f();
+        const int r0 = doy_start[d], r1 = doy_start[d + 1];
+        for (int r = r0; r < r1; ++r) {
+            const size_t off = (size_t)doy_rows[r] * C + c;
+            out[off] = anom[off] / safe;
+        }
+    }
+}
+
+extern "C" int marex_std_rolling_doy_f32(marex_ctx* ctx, const float* anom, int64_t T, int64_t C,
+                                         const int32_t* doy_start, const int32_t* doy_rows, int window,
+                                         float* std_day, float* std_roll) {
+    if (!ctx) return -1;
+    if (!anom || !doy_start || !doy_rows || !std_day || !std_roll || T <= 0 || C <= 0)
+        return fail(ctx, -1, "marex_std_rolling_doy_f32: null pointer or empty shape");
+    if (window < 1 || window > NDOY) return fail(ctx, -1, "marex_std_rolling_doy_f32: window must be in 1..366");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((C + 255) / 256), NDOY);
+    {
+        LaunchTimer lt(ctx, MAREX_K_STDNORM);
+        hipLaunchKernelGGL(k_doy_std, grid, dim3(256), 0, ctx->stream, anom, doy_start, doy_rows, (long)C, std_day);
+        hipLaunchKernelGGL(k_std_rolling, grid, dim3(256), 0, ctx->stream, std_day, (long)C, window, std_roll);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int marex_div_doy_f32(marex_ctx* ctx, const float* anom, const float* std_roll, const int32_t* doy_start,
+                                 const int32_t* doy_rows, int64_t T, int64_t C, float* out) {
+    if (!ctx) return -1;
+    if (!anom || !std_roll || !doy_start || !doy_rows || !out || T <= 0 || C <= 0)
+        return fail(ctx, -1, "marex_div_doy_f32: null pointer or empty shape");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((C + 255) / 256), MASK_DOY_CHUNKS);
+    {
+        LaunchTimer lt(ctx, MAREX_K_STDNORM);
+        hipLaunchKernelGGL(k_div_doy, grid, dim3(256), 0, ctx->stream, anom, std_roll, doy_start, doy_rows, (long)C, out);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,212 @@
+// marex_mask.hip -- extreme mask kernels and the threshold transpose
+#include "marex_common.hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// K_M: extreme[t, c] = anom[t, c] >= thr[doy(t), c]
+// One workgroup = (VEC*256 cells, a chunk of consecutive dayofyears).  Rows are visited grouped by
+// dayofyear so that one threshold row serves all its timesteps out of registers; 16-byte loads of the
+// anomaly row, 4-byte stores of the mask, MASK_UNROLL independent rows in flight per lane.
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256)
+k_mask_ge(const float* __restrict__ anom, const float* __restrict__ thr, const int* __restrict__ doy_start,
+          const int* __restrict__ doy_rows, long C, long c0, long c1, unsigned char* __restrict__ out,
+          unsigned long long* __restrict__ n_true) {
+    const int nchunk = (int)gridDim.y;  // the dayofyear axis is cut into gridDim.y pieces
+    const int dA = (int)blockIdx.y * NDOY / nchunk, dB = ((int)blockIdx.y + 1) * NDOY / nchunk;
+    const long c = c0 + ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    unsigned cnt = 0;
+    if (c < c1) {
+        for (int d = dA; d < dB; ++d) {
+            const int r0 = doy_start[d], r1 = doy_start[d + 1];
+            if (VEC == 4) {
+                const float4 th = *reinterpret_cast<const float4*>(thr + (size_t)d * C + c);
+                int r = r0;
+                for (; r + 4 <= r1; r += 4) {
+                    size_t off[4];
+                    float4 a[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) off[u] = (size_t)doy_rows[r + u] * C + c;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        typedef float f4_t __attribute__((ext_vector_type(4)));
+                        const f4_t q4 = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(anom + off[u]));
+                        a[u] = make_float4(q4.x, q4.y, q4.z, q4.w);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        uchar4 m;
+                        m.x = a[u].x >= th.x;
+                        m.y = a[u].y >= th.y;
+                        m.z = a[u].z >= th.z;
+                        m.w = a[u].w >= th.w;
+                        cnt += m.x + m.y + m.z + m.w;
+                        __builtin_nontemporal_store((unsigned)m.x | ((unsigned)m.y << 8) | ((unsigned)m.z << 16) | ((unsigned)m.w << 24),
+                                                    reinterpret_cast<unsigned*>(out + off[u]));
+                    }
+                }
+                for (; r < r1; ++r) {
+                    const size_t off = (size_t)doy_rows[r] * C + c;
+                    const float4 a = *reinterpret_cast<const float4*>(anom + off);
+                    uchar4 m;
+                    m.x = a.x >= th.x;
+                    m.y = a.y >= th.y;
+                    m.z = a.z >= th.z;
+                    m.w = a.w >= th.w;
+                    cnt += m.x + m.y + m.z + m.w;
+                    *reinterpret_cast<uchar4*>(out + off) = m;
+                }
+            } else {
+                const float th = thr[(size_t)d * C + c];
+                for (int r = r0; r < r1; ++r) {
+                    const size_t off = (size_t)doy_rows[r] * C + c;
+                    const unsigned char m = anom[off] >= th;
+                    cnt += m;
+                    out[off] = m;
+                }
+            }
+        }
+    }
+    if (n_true) {
+        for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s, 64);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(n_true, (unsigned long long)cnt);
+    }
+}
+
+extern "C" int marex_mask_ge_doy_f32(marex_ctx* ctx, const float* anom, const float* thr_doy_major,
+                                     const int32_t* doy_start, const int32_t* doy_rows, int64_t T_out, int64_t C,
+                                     int64_t c0, int64_t c1, uint8_t* extreme, unsigned long long* n_true) {
+    if (!ctx) return -1;
+    if (!anom || !thr_doy_major || !doy_start || !doy_rows || !extreme || T_out <= 0 || C <= 0)
+        return fail(ctx, -1, "marex_mask_ge_doy_f32: null pointer or empty shape");
+    if (c0 < 0 || c1 > C || c0 >= c1) return fail(ctx, -1, "marex_mask_ge_doy_f32: need 0 <= c0 < c1 <= C");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t nc = c1 - c0;
+    const bool vec = (C % 4 == 0) && (c0 % 4 == 0) && (c1 % 4 == 0) && (((uintptr_t)anom | (uintptr_t)thr_doy_major) % 16 == 0) && ((uintptr_t)extreme % 4 == 0);
+    {
+        LaunchTimer lt(ctx, MAREX_K_MASK);
+        if (vec) {
+            // enough workgroups to fill the chip whatever the number of cells (a 100-yr latitude band has 133 cell blocks)
+            const unsigned ncb4 = (unsigned)((nc / 4 + 255) / 256);
+            unsigned chunks = (4096 + ncb4 - 1) / ncb4;
+            chunks = chunks < MASK_DOY_CHUNKS ? MASK_DOY_CHUNKS : (chunks > 61 ? 61 : chunks);
+            dim3 grid(ncb4, chunks);
+            hipLaunchKernelGGL(k_mask_ge<4>, grid, dim3(256), 0, ctx->stream, anom, thr_doy_major, doy_start, doy_rows,
+                               (long)C, (long)c0, (long)c1, extreme, n_true);
+        } else {
+            dim3 grid((unsigned)((nc + 255) / 256), MASK_DOY_CHUNKS);
+            hipLaunchKernelGGL(k_mask_ge<1>, grid, dim3(256), 0, ctx->stream, anom, thr_doy_major, doy_start, doy_rows,
+                               (long)C, (long)c0, (long)c1, extreme, n_true);
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+__global__ void __launch_bounds__(256)
+k_mask_ge_const(const float* __restrict__ anom, const double* __restrict__ thr, long T, long C, int rows_per_block,
+                unsigned char* __restrict__ out, unsigned long long* __restrict__ n_true) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    unsigned cnt = 0;
+    if (c < C) {
+        const double th = thr[c];
+        const long t0 = (long)blockIdx.y * rows_per_block;
+        const long t1 = t0 + rows_per_block < T ? t0 + rows_per_block : T;
+        for (long t = t0; t < t1; ++t) {
+            const unsigned char m = (double)anom[(size_t)t * C + c] >= th;
+            cnt += m;
+            out[(size_t)t * C + c] = m;
+        }
+    }
+    if (n_true) {
+        for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s, 64);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(n_true, (unsigned long long)cnt);
+    }
+}
+
+// four cells per lane: 16-byte anomaly loads, 4-byte mask stores, four rows in flight
+__global__ void __launch_bounds__(256)
+k_mask_ge_const4(const float* __restrict__ anom, const double* __restrict__ thr, long T, long C, int rows_per_block,
+                 unsigned char* __restrict__ out, unsigned long long* __restrict__ n_true) {
+    const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    unsigned cnt = 0;
+    if (c < C) {
+        const double t0d = thr[c], t1d = thr[c + 1], t2d = thr[c + 2], t3d = thr[c + 3];
+        const long t0 = (long)blockIdx.y * rows_per_block;
+        const long t1 = t0 + rows_per_block < T ? t0 + rows_per_block : T;
+        auto one = [&](long t, float4 a) {
+            uchar4 m;
+            m.x = (double)a.x >= t0d;
+            m.y = (double)a.y >= t1d;
+            m.z = (double)a.z >= t2d;
+            m.w = (double)a.w >= t3d;
+            cnt += m.x + m.y + m.z + m.w;
+            *reinterpret_cast<uchar4*>(out + (size_t)t * C + c) = m;
+        };
+        long t = t0;
+        for (; t + 4 <= t1; t += 4) {
+            float4 a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(anom + (size_t)(t + u) * C + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) one(t + u, a[u]);
+        }
+        for (; t < t1; ++t) one(t, *reinterpret_cast<const float4*>(anom + (size_t)t * C + c));
+    }
+    if (n_true) {
+        for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s, 64);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(n_true, (unsigned long long)cnt);
+    }
+}
+
+extern "C" int marex_mask_ge_const_f32(marex_ctx* ctx, const float* anom, const double* thr, int64_t T_out, int64_t C,
+                                       uint8_t* extreme, unsigned long long* n_true) {
+    if (!ctx) return -1;
+    if (!anom || !thr || !extreme || T_out <= 0 || C <= 0) return fail(ctx, -1, "marex_mask_ge_const_f32: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rows = 64;
+    {
+        LaunchTimer lt(ctx, MAREX_K_MASK);
+        if ((C & 3) == 0) {
+            dim3 grid((unsigned)((C / 4 + 255) / 256), (unsigned)((T_out + rows - 1) / rows));
+            hipLaunchKernelGGL(k_mask_ge_const4, grid, dim3(256), 0, ctx->stream, anom, thr, (long)T_out, (long)C, rows, extreme, n_true);
+        } else {
+            dim3 grid((unsigned)((C + 255) / 256), (unsigned)((T_out + rows - 1) / rows));
+            hipLaunchKernelGGL(k_mask_ge_const, grid, dim3(256), 0, ctx->stream, anom, thr, (long)T_out, (long)C, rows, extreme, n_true);
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// transpose (thresholds [366, C] -> [C, 366])
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ in, long rows, long cols,
+                                                   float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const long c0 = (long)blockIdx.x * 32, r0 = (long)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const long r = r0 + k, c = c0 + tx;
+        if (r < rows && c < cols) tile[k][tx] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const long c = c0 + k, r = r0 + tx;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][k];
+    }
+}
+
+extern "C" int marex_transpose_f32(marex_ctx* ctx, const float* in, int64_t rows, int64_t cols, float* out) {
+    if (!ctx) return -1;
+    if (!in || !out || rows <= 0 || cols <= 0) return fail(ctx, -1, "marex_transpose_f32: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    {
+        LaunchTimer lt(ctx, MAREX_K_TRANSPOSE);
+        hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, ctx->stream, in, (long)rows, (long)cols, out);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

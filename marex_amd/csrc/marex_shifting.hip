@@ -1,0 +1,744 @@
+// marex_shifting.hip -- K_A: validation + smoothing + rolling climatology + anomaly + bins
+#include "marex_common.hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// K_A: shifting-baseline anomaly  (smoothing + rolling climatology + anomaly + bins + validation)
+//
+// Work item = (block of 256 consecutive cells, chunk of D consecutive dayofyears).  The workgroup
+// walks the calendar years in ascending order.  For one year the D dayofyears of the chunk are D
+// consecutive timesteps, so ONE load of D+S-1 rows (256 contiguous floats each) feeds the S-step
+// smoothing of all D days out of registers.  The W-year history of every (cell, dayofyear) lives in
+// an LDS ring [D][W][256] that is private per lane (no barriers in the year loop).  Each input row
+// is read by ceil((D+S-1)/D) chunks; blocks of one cell block are placed on one XCD so that those
+// re-reads are L2 / Infinity-Cache hits and HBM sees every byte of x about once.
+// ------------------------------------------------------------------------------------------------
+template <int D, int SCAP, bool SEXACT, int WCAP, bool RREG>
+__global__ void __launch_bounds__(256)
+k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__ year_plan, int n_cal, int W,
+           int S_rt, int write_clim, const float* __restrict__ edges, int nb, long T_out, float* __restrict__ out,
+           unsigned short* __restrict__ bins, unsigned char* __restrict__ mask, int* __restrict__ invalid_count,
+           int ncb, int nchunks, int ablate, const int* __restrict__ skip) {
+    extern __shared__ float lds[];
+    // W-year history of every (cell, dayofyear).  LDS ring [D][WCAP][256] (slots W..WCAP-1 hold +0.0, neutral in
+    // the sum), or -- RREG -- a register shift line per dayofyear: rr[i][WCAP-W .. WCAP-1] = years y-W .. y-1,
+    // the leading WCAP-W entries stay +0.0.  The register line frees the LDS, so occupancy is set by VGPRs only.
+    float* ring = lds;
+    float rr[RREG ? D : 1][RREG ? WCAP : 1];
+    const int npad = WCAP - W;
+    int4* lplan = reinterpret_cast<int4*>(lds + (RREG ? (size_t)0 : (size_t)D * WCAP * 256));  // [n_cal][D] plan column
+    float* e = reinterpret_cast<float*>(lplan + (size_t)n_cal * D);      // [nb+1] when binning
+
+    int cb, chunk;
+    if (!xcd_swizzle(blockIdx.x, ncb, nchunks, cb, chunk)) return;
+    if (D == 4 && skip && skip[chunk]) return;  // this chunk of 4 dayofyears belongs to k_shift_fast
+    const int tid = threadIdx.x;
+    const long c = (long)cb * 256 + tid;
+    const bool active = c < C;
+    const int S = SEXACT ? SCAP : S_rt;
+    const int lo = S / 2;
+    const float Sf = (float)S;
+    const int d0 = chunk * D;
+    const bool do_bins = bins != nullptr;
+
+    if (RREG) {
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < WCAP; ++j) rr[i][j] = j >= npad ? nan_f() : 0.f;
+    } else if (!(ablate & 128)) {
+        for (int i = tid; i < D * WCAP * 256; i += 256) ring[i] = ((i >> 8) % WCAP) < W ? nan_f() : 0.f;
+    }
+    // ring_read: the W history values in ascending year order plus the +0.0 pads (LDS: pads last, RREG: pads first;
+    // adding +0.0 before or after changes nothing: the sum starts at +0.0).  ring_push: year y replaces year y-W.
+    auto ring_read = [&](int i, int slot0, float (&rv)[WCAP]) {
+        if (RREG) {
+#pragma unroll
+            for (int j = 0; j < WCAP; ++j) rv[j] = rr[i][j];
+        } else {
+            const float* col = ring + (size_t)i * WCAP * 256 + tid;
+#pragma unroll
+            for (int j = 0; j < WCAP; ++j) {
+                int sl = slot0 + j;
+                sl = sl >= W ? sl - W : sl;
+                sl = j < W ? sl : j;
+                rv[j] = col[sl * 256];
+            }
+        }
+    };
+    auto ring_push = [&](int i, int slot0, float v) {
+        if (RREG) {
+#pragma unroll
+            for (int j = 0; j < WCAP - 1; ++j) rr[i][j] = j >= npad ? rr[i][j + 1] : 0.f;
+            rr[i][WCAP - 1] = v;
+        } else {
+            ring[((size_t)i * WCAP + slot0) * 256 + tid] = v;
+        }
+    };
+    auto is_real = [&](int j) { return RREG ? j >= npad : j < W; };
+    // the chunk's {timestep, output row, bin row} entries of every year, staged once: the year loop then reads
+    // them from LDS instead of waiting on a scalar global load per year (dayofyears past 366 count as absent)
+    for (int i = tid; i < n_cal * D; i += 256) {
+        const int y = i / D, k = i - y * D;
+        lplan[i] = (d0 + k < NDOY) ? year_plan[(size_t)y * NDOY + d0 + k] : make_int4(-1, -1, -1, 0);
+    }
+    if (do_bins)
+        for (int i = tid; i <= nb; i += 256) e[i] = edges[i];
+    __syncthreads();
+    float inv_width = 0.f, e_first = 0.f, e_delta = 0.f, e_last = 0.f;
+    bool arange_tab = false;
+    if (do_bins) {
+        inv_width = (float)(nb - 1) / (e[nb] - e[1]);
+        e_first = e[1];
+        e_delta = e[2] - e[1];
+        e_last = e[nb];
+        arange_tab = edges_are_arange(e, nb) && !(ablate & 512);
+    }
+
+    int n_invalid = 0;
+    if (chunk == 0 && mask && active) mask[c] = finite_f(x[c]) ? 1 : 0;
+    if (ablate & 256) return;  // timing only: launch + init
+    // Inactive lanes (beyond C) stream -- and store -- the last cell instead of being masked off: loads and
+    // stores stay unconditional and uniform in control flow (duplicate stores write identical values).
+    const unsigned cidx = active ? (unsigned)c : (unsigned)(C - 1);
+
+    // One (dayofyear i, year y) element: climatology from the ring, anomaly, bin, then push s into the ring.
+    // pl = {timestep, output row, bin-matrix row} (-1: none).  The ring is read with NO predicates: the slots
+    // of years y-W .. y-1 in ascending order (slot0, slot0+1, ... mod W), then the +0.0 pad slots.
+    auto emit = [&](int i, int slot0, const int4 pl, float xc, float s) {
+        if (ablate & 1) {  // timing only: keep the inputs alive, skip climatology / anomaly / bins / stores
+            if (xc + s == 12345.678f) out[cidx] = xc;
+            return;
+        }
+        if (pl.x >= 0) {  // uniform
+            n_invalid += finite_f(xc) ? 0 : 1;
+            if (pl.y >= 0) {  // uniform: this timestep is an output row
+                float rv[WCAP];
+                float acc = 0.f;
+                int n = W;
+                if (ablate & 8) {
+                    acc = s;
+                } else {
+                    ring_read(i, slot0, rv);
+#pragma unroll
+                    for (int j = 0; j < WCAP; ++j) acc += rv[j];
+                    // a NaN term (leap day, first days of the series, gaps): redo as nanmean.  Land lanes (NaN
+                    // centre value) never need it -- their anomaly is NaN whatever the climatology is.
+                    if (!(acc == acc) && (write_clim || xc == xc)) {
+                        acc = 0.f;
+                        n = 0;
+#pragma unroll
+                        for (int j = 0; j < WCAP; ++j) {
+                            if (is_real(j) && rv[j] == rv[j]) {
+                                acc += rv[j];
+                                ++n;
+                            }
+                        }
+                    }
+                }
+                const float clim = (ablate & 16) ? acc : acc / (float)n;  // n == 0 -> 0/0 = NaN
+                const float a = xc - clim;
+                // lanes beyond C duplicate the last cell (same inputs, same values): stores need no guard
+                if (!(ablate & 64)) out[(size_t)pl.y * C + cidx] = write_clim ? clim : a;
+                if (do_bins && !(ablate & 32))
+                    bins[(ablate & 1024) ? (size_t)cidx : bins_index(pl.z, cidx, T_out)] = (unsigned short)(
+                        arange_tab ? digitize_arange(a, e_first, e_delta, e_last, nb, inv_width)
+                                   : digitize_bin(a, e, nb, inv_width));
+                if ((ablate & 96) == 96 && a == 12345.678f) out[cidx] = a;
+            }
+        }
+        ring_push(i, slot0, (pl.x >= 0) ? s : nan_f());
+    };
+
+    // The same for all D dayofyears of a year at once, phase by phase, so that the D independent dependency
+    // chains (ring sums, divisions, bin search) overlap instead of running one after the other.  Used when every
+    // one of the D timesteps is an output row (the common case after the first W years).
+    auto emit_all = [&](int slot0, const int4 (&pl)[D], const float (&xc)[D], const float (&sm)[D]) {
+        float rv[D][WCAP];
+#pragma unroll
+        for (int i = 0; i < D; ++i) ring_read(i, slot0, rv[i]);
+        float acc[D];
+        int n[D];
+        bool slow = false;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            acc[i] = 0.f;
+            n[i] = W;
+            n_invalid += finite_f(xc[i]) ? 0 : 1;
+        }
+#pragma unroll
+        for (int j = 0; j < WCAP; ++j)
+#pragma unroll
+            for (int i = 0; i < D; ++i) acc[i] += rv[i][j];
+#pragma unroll
+        for (int i = 0; i < D; ++i) slow |= !(acc[i] == acc[i]) && (write_clim || xc[i] == xc[i]);
+        if (slow) {  // a NaN term somewhere (leap day, first days of the series, gaps): nanmean for those
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                if (!(acc[i] == acc[i]) && (write_clim || xc[i] == xc[i])) {
+                    acc[i] = 0.f;
+                    n[i] = 0;
+#pragma unroll
+                    for (int j = 0; j < WCAP; ++j) {
+                        if (is_real(j) && rv[i][j] == rv[i][j]) {
+                            acc[i] += rv[i][j];
+                            ++n[i];
+                        }
+                    }
+                }
+            }
+        }
+        float a[D], clim[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            clim[i] = acc[i] / (float)n[i];  // n == 0 -> 0/0 = NaN
+            a[i] = xc[i] - clim[i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) out[(size_t)pl[i].y * C + cidx] = write_clim ? clim[i] : a[i];
+        if (do_bins) {
+            int kb[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+                kb[i] = arange_tab ? digitize_arange(a[i], e_first, e_delta, e_last, nb, inv_width)
+                                   : digitize_bin(a[i], e, nb, inv_width);
+#pragma unroll
+            for (int i = 0; i < D; ++i) bins[bins_index(pl[i].z, cidx, T_out)] = (unsigned short)kb[i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) ring_push(i, slot0, sm[i]);
+    };
+
+    constexpr int NL = D + SCAP - 1;
+    float xw[NL];
+    for (int y = 0; y < n_cal; ++y) {
+        // this year's D plan entries (dayofyears past 366 in the last chunk count as absent)
+        int4 pl[D];
+        bool fast = true, any = false;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            pl[i] = lplan[y * D + i];
+            any |= pl[i].x >= 0;
+            fast &= (pl[i].x >= 0) && (pl[i].x == pl[0].x + i);
+        }
+        if (!RREG && !any && y < W) continue;  // nothing to read, and the ring slot of this year still holds its initial NaN
+        const int slot0 = y % W;
+        const long r0 = (long)pl[0].x - lo;
+        if (fast && SEXACT && r0 >= 0 && r0 + NL <= T) {
+            // D consecutive timesteps, whole batch inside the series: NL unconditional row loads, no predicates
+            if (ablate & 4) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) xw[j] = (float)(j + y) * 0.25f;
+            } else {
+                const float* rowp = x + (size_t)r0 * C;
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    xw[j] = rowp[cidx];
+                    rowp += C;
+                }
+            }
+            float sacc[D], xcen[D], smo[D];
+            bool all_out = !ablate;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                sacc[i] = xw[i];
+                xcen[i] = xw[i + SCAP / 2];
+                all_out &= pl[i].y >= 0;
+            }
+            if (ablate & 2) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) sacc[i] = xw[i] + xw[NL - 1];
+            } else {
+#pragma unroll
+                for (int k = 1; k < SCAP; ++k)
+#pragma unroll
+                    for (int i = 0; i < D; ++i) sacc[i] += xw[i + k];
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) smo[i] = sacc[i] / Sf;
+            if (all_out) {
+                emit_all(slot0, pl, xcen, smo);
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; ++i) emit(i, slot0, pl[i], xcen[i], smo[i]);
+            }
+        } else {
+            // generic path: every present dayofyear loads its own S rows with range checks (series ends,
+            // calendar gaps, leap day, runtime S)
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                float xc = nan_f(), sm = nan_f();
+                if (pl[i].x >= 0) {
+                    const long q0 = (long)pl[i].x - lo;
+                    float acc = 0.f;
+                    for (int k = 0; k < S; ++k) {
+                        const long row = q0 + k;
+                        const float v = (row >= 0 && row < T) ? x[(size_t)row * C + cidx] : nan_f();
+                        acc = (k == 0) ? v : acc + v;
+                        if (k == lo) xc = v;
+                    }
+                    sm = acc / Sf;
+                }
+                emit(i, slot0, pl[i], xc, sm);
+            }
+        }
+    }
+    if (invalid_count && active && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_A fast path: the same arithmetic as k_shifting for the regular part of the calendar, written for
+// the VALU (which is what bounds k_shifting: 386 vector instructions per wave, year and 4 dayofyears).
+//
+//   * wave = 64 cells x 4 consecutive dayofyears; the 4 waves of a workgroup take 4 neighbouring
+//     chunks of the SAME 64 cells.  Everything about the calendar is wave-uniform and lives in SGPRs
+//     (the plan is read with scalar loads one year ahead), so row addresses are SGPR base + lane offset.
+//   * two dayofyears per instruction: packed float32 (v_pk_add/mul/fma_f32).  The two smoothing chains
+//     of a pair are skewed by one step so that both add the SAME row in one instruction (op_sel
+//     broadcast) -- 23 instructions for the 40 sequential adds of a pair, bit-identical to the
+//     sequential sums (the lagging chain starts from -0.0, the identity of IEEE addition).
+//   * "/ S" and "/ W" are a * fl(1/b) followed by one Markstein correction step (two fma) and
+//     v_div_fixup_f32 for zeros / infinities: bit-identical to IEEE division for every float32 a when b
+//     is odd or a power of two (exhaustive check over b <= 64: oracle/proofs/div_by_const.c; even b
+//     have ties among subnormal quotients and keep the real division).
+//   * np.digitize on an arange table: one fused guess, two edges recomputed with the table's own
+//     arithmetic, +-1 correction (classify() proves the guess is within one bin before enabling this).
+//   * the W-year history is a register shift line of exactly W packed pairs (template parameter).
+// Chunks the calendar makes irregular (leap day, gaps, series starting mid-chunk) and every other
+// configuration (S != 21, W > 16, arbitrary edge tables) stay on k_shifting; k_shift_classify decides
+// per chunk on the device, both kernels skip the other's chunks.
+// ------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// acc.lo += src.lo, acc.hi += src.lo  /  acc.lo += src.hi, acc.hi += src.hi
+__device__ __forceinline__ v2f pk_add_bc_lo(v2f acc, v2f src) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(acc), "v"(src));
+    return r;
+}
+__device__ __forceinline__ v2f pk_add_bc_hi(v2f acc, v2f src) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(acc), "v"(src));
+    return r;
+}
+__device__ __forceinline__ v2f splat2(float v) { return (v2f){v, v}; }
+
+// a / b for a constant b (y = fl(1/b)): bit-identical to IEEE division for odd b and powers of two up to 64
+// (exhaustive over all 2^32 a: oracle/proofs/div_by_const.c; v_div_fixup supplies the +-0 and +-inf cases)
+__device__ __forceinline__ v2f div_const2(v2f a, float b, float y) {
+    const v2f q = a * splat2(y);
+    const v2f r = __builtin_elementwise_fma(-q, splat2(b), a);
+    const v2f q2 = __builtin_elementwise_fma(r, splat2(y), q);
+    return (v2f){__builtin_amdgcn_div_fixupf(q2.x, b, a.x), __builtin_amdgcn_div_fixupf(q2.y, b, a.y)};
+}
+
+// Buffer addressing: 128-bit descriptor in SGPRs (wave-uniform base), 32-bit lane byte offset in a VGPR, 32-bit
+// uniform byte offset in an SGPR -- no vector instruction is spent on addresses.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float ldb_f32(rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+// cache policy of the anomaly stores: non-temporal (bit 1) -- the rows are never read again by this kernel, keeping
+// them out of the L2 leaves it to the input rows that neighbouring workgroups re-read (measured -5 % on a 100-yr band;
+// the same hint on the 2-byte bin stores is 15 % slower)
+#ifndef ST_AUX_F32
+#define ST_AUX_F32 2
+#endif
+#ifndef ST_AUX_U16
+#define ST_AUX_U16 0
+#endif
+__device__ __forceinline__ void stb_f32(rsrc_t r, unsigned voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, soff, ST_AUX_F32);
+}
+__device__ __forceinline__ void stb_u16(rsrc_t r, unsigned voff, int soff, int v) {
+    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, r, (int)voff, soff, ST_AUX_U16);
+}
+
+#define SHIFT_INFO_WORDS 128  // [0..91] chunk handled by the fast kernel, [92] arange edges usable
+
+__global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, const float* __restrict__ edges, int nb,
+                                 int want_bins, int enable, int* __restrict__ info) {
+    __shared__ int s_edges_ok;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        int ok = 1;
+        if (want_bins) {
+            const float first = edges[1], delta = edges[2] - edges[1], last = edges[nb];
+            ok = delta > 0.f && nb < 32768;
+            for (int j = 1; ok && j <= nb; ++j)
+                ok = __float_as_uint(edges[j]) == __float_as_uint(arange_edge(j, first, delta));
+            // the fused guess (biased down by 1/128 bin) must land in the true bin or the one below: generous bound
+            // on its rounding error (about 8x what the individual roundings add up to)
+            const double m = fabs((double)first) > fabs((double)last) ? fabs((double)first) : fabs((double)last);
+            ok = ok && ((double)nb + 2.0 * m / (double)delta) * (1.0 / 1048576.0) < 1.0 / 256.0;
+        }
+        s_edges_ok = ok && enable;
+        info[92] = s_edges_ok;
+    }
+    __syncthreads();
+    if (t >= 92) return;
+    const int d0 = t * 4;
+    int ok = s_edges_ok;
+    // every year: the first m (0..4) dayofyears of the chunk present on consecutive timesteps, the rest absent
+    // (leap day; dayofyears past 366 in the last chunk); output rows all or none, consecutive
+    for (int y = 0; ok && y < n_cal; ++y) {
+        int4 e[4];
+        for (int i = 0; i < 4; ++i)
+            e[i] = (d0 + i < NDOY) ? year_plan[(size_t)y * NDOY + d0 + i] : make_int4(-1, -1, -1, 0);
+        int m = 0;
+        while (m < 4 && e[m].x >= 0) ++m;
+        for (int i = m; i < 4; ++i) ok = ok && e[i].x < 0;
+        for (int i = 1; i < m; ++i) {
+            ok = ok && e[i].x == e[0].x + i;
+            if (e[0].y >= 0)
+                ok = ok && e[i].y == e[0].y + i && e[i].z >= 0;
+            else
+                ok = ok && e[i].y < 0;
+        }
+        if (m > 0 && e[0].y >= 0) ok = ok && e[0].z >= 0;
+    }
+    info[t] = ok;
+}
+
+template <int W>
+__global__ void __launch_bounds__(256)
+k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict__ year_plan, int n_cal,
+             const int* __restrict__ info, int write_clim, const float* __restrict__ edges, int nb, long T_out, float* __restrict__ out, unsigned short* __restrict__ bins, unsigned char* __restrict__ mask,
+             int* __restrict__ invalid_count, int ncg, int nblk) {
+    int cg, bc;
+    if (!xcd_swizzle(blockIdx.x, ncg, nblk, cg, bc)) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int chunk = bc * 4 + wave;
+    // The 4 waves work on 4 neighbouring chunks of the same 64 cells: the 36 rows one calendar year needs for
+    // all 16 dayofyears are staged once in LDS (double buffered, loaded one year ahead) and every wave reads its
+    // 24 from there -- 2.25 instead of 6 row reads per output row leave the L2.
+    __shared__ float stage[2][36 * 64];
+    const bool mine = chunk < 92 && info[chunk] != 0;  // wave-uniform; the other waves only help staging
+    const int d0 = mine ? chunk * 4 : 0;
+    const int4* pblk = year_plan + bc * 16;  // first dayofyear of the workgroup (bc <= 22: always < 366)
+    const long c = (long)cg * 64 + lane;
+    const bool active = c < C;
+    const unsigned cidx = active ? (unsigned)c : (unsigned)(C - 1);  // lanes beyond C duplicate the last cell
+    const bool do_bins = bins != nullptr;
+    // bin matrix: lane part of the element index relative to the wave's first 16-cell block
+    const unsigned voff = cidx * 4u;  // byte offset of the lane's cell inside a (time, cell) row
+    const int rowb = (int)(C * 4);    // bytes per (time, cell) row
+    const unsigned bin_lane = (((cidx >> 4) - (unsigned)(cg * 4)) * (unsigned)T_out * 16u + (cidx & 15u)) * 2u;  // bytes
+    const rsrc_t rbins = make_rsrc(do_bins ? bins + (size_t)(cg * 4) * (size_t)T_out * 16 : nullptr);
+
+    float e_first = 0.f, e_delta = 1.f, inv_width = 1.f;
+    if (do_bins) {
+        e_first = edges[1];
+        e_delta = edges[2] - edges[1];
+        inv_width = (float)(nb - 1) / (edges[nb] - e_first);
+    }
+    constexpr float Sf = 21.f;
+    const float yS = 1.0f / Sf;
+    const float Wf = (float)W;
+    const float yW = 1.0f / Wf;
+    const float nbm1f = (float)(nb - 1);
+    const float c0 = (1.0f - e_first * inv_width) - 0.0078125f;  // +1 (edges[0] = -inf) and the 1/128-bin downward bias
+    const float qnan = nan_f();
+
+    if (chunk == 0 && mine && mask && active) mask[c] = finite_f(x[c]) ? 1 : 0;
+    // rows tb-10 .. tb+25 (tb = timestep of the workgroup's first dayofyear in that year) can be staged when they
+    // all lie inside the series; this wave loads rows 9*wave .. 9*wave+8 of them
+    auto stage_ok = [&](int tb) { return tb >= 10 && (long)tb + 26 <= T; };
+    auto stage_load = [&](int tb, float (&nx)[9]) {
+        const rsrc_t rs = make_rsrc(x + (size_t)(tb - 10 + 9 * wave) * C);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) nx[k] = ldb_f32(rs, voff, k * rowb);
+    };
+    auto stage_store = [&](int buf, const float (&nx)[9]) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) stage[buf][(9 * wave + k) * 64 + lane] = nx[k];
+    };
+    int tb_next = pblk[0].x;
+    {
+        float nx[9];
+        if (stage_ok(tb_next)) {
+            stage_load(tb_next, nx);
+            stage_store(0, nx);
+        }
+    }
+    __syncthreads();
+
+    // History of dayofyears (0,1) and (2,3) as register lines.  The year loop is unrolled by two: the first year of a
+    // pair reads entries [0, W) and appends at [W], the second reads [1, W] and appends at [W+1], then the line moves
+    // down by two -- W moves per two years instead of 2 (W - 1).
+    v2f rA[W + 2], rB[W + 2];
+#pragma unroll
+    for (int j = 0; j < W + 2; ++j) rA[j] = rB[j] = splat2(qnan);
+    int n_invalid = 0;
+
+    const int4* pp = year_plan + d0;
+    const bool tail = d0 + 3 >= NDOY;  // last chunk: dayofyears 365, 366 and two that do not exist
+    const int4 absent = make_int4(-1, -1, -1, 0);
+    int4 n0 = pp[0], n1 = pp[1], n2 = tail ? absent : pp[2], n3 = tail ? absent : pp[3];
+    auto one_year = [&](int y, auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        const int4 p0 = n0, p1 = n1, p2 = n2, p3 = n3;
+        const int tb = tb_next;
+        float nx[9];
+        bool stage_next = false;
+        if (y + 1 < n_cal) {  // next year's plan and rows, one iteration ahead
+            const int4* q = pp + (size_t)(y + 1) * NDOY;
+            n0 = q[0];
+            n1 = q[1];
+            n2 = tail ? absent : q[2];
+            n3 = tail ? absent : q[3];
+            tb_next = pblk[(size_t)(y + 1) * NDOY].x;
+            stage_next = stage_ok(tb_next);
+            if (stage_next) stage_load(tb_next, nx);
+        }
+        v2f smA = splat2(qnan), smB = splat2(qnan);
+        if (mine && p0.x >= 0) {
+            const long r0 = (long)p0.x - 10;
+            v2f xp[12];  // xp[m] = rows (r0 + 2m, r0 + 2m + 1)
+            const bool edge = r0 < 0 || r0 + 24 > T;
+            if (stage_ok(tb) && p0.x == tb + 4 * wave) {
+                const float* st = &stage[y & 1][(4 * wave) * 64 + lane];
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    xp[m].x = st[(2 * m) * 64];
+                    xp[m].y = st[(2 * m + 1) * 64];
+                }
+            } else if (!edge) {
+                const rsrc_t rx = make_rsrc(x + (size_t)r0 * C);
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    xp[m].x = ldb_f32(rx, voff, (2 * m) * rowb);
+                    xp[m].y = ldb_f32(rx, voff, (2 * m + 1) * rowb);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    long ra = r0 + 2 * m, rb = ra + 1;
+                    ra = ra < 0 ? 0 : (ra > T - 1 ? T - 1 : ra);
+                    rb = rb < 0 ? 0 : (rb > T - 1 ? T - 1 : rb);
+                    xp[m].x = ldb_f32(make_rsrc(x + (size_t)ra * C), voff, 0);
+                    xp[m].y = ldb_f32(make_rsrc(x + (size_t)rb * C), voff, 0);
+                }
+            }
+            // smoothing: sequential sums of rows i .. i+20 for the four dayofyears i = 0..3
+            v2f accA = (v2f){xp[0].x, -0.0f};
+#pragma unroll
+            for (int s = 1; s <= 20; ++s) accA = (s & 1) ? pk_add_bc_hi(accA, xp[s >> 1]) : pk_add_bc_lo(accA, xp[s >> 1]);
+            accA.y += xp[10].y;
+            v2f accB = (v2f){xp[1].x, -0.0f};
+#pragma unroll
+            for (int s = 3; s <= 22; ++s) accB = (s & 1) ? pk_add_bc_hi(accB, xp[s >> 1]) : pk_add_bc_lo(accB, xp[s >> 1]);
+            accB.y += xp[11].y;
+            smA = div_const2(accA, Sf, yS);
+            smB = div_const2(accB, Sf, yS);
+            if (edge) {  // windows that leave the series: NaN (a NaN row in the sum, in the general kernel)
+                const long t0 = p0.x;
+                smA.x = (t0 - 10 >= 0 && t0 + 10 < T) ? smA.x : qnan;
+                smA.y = (t0 - 9 >= 0 && t0 + 11 < T) ? smA.y : qnan;
+                smB.x = (t0 - 8 >= 0 && t0 + 12 < T) ? smB.x : qnan;
+                smB.y = (t0 - 7 >= 0 && t0 + 13 < T) ? smB.y : qnan;
+            }
+            const v2f xcA = xp[5], xcB = xp[6];
+            const bool partial = p3.x < 0;  // only a prefix of the 4 dayofyears exists this year (leap day chunk)
+            if (!partial) {
+                n_invalid += (finite_f(xcA.x) ? 0 : 1) + (finite_f(xcA.y) ? 0 : 1) + (finite_f(xcB.x) ? 0 : 1) +
+                             (finite_f(xcB.y) ? 0 : 1);
+            } else {
+                n_invalid += finite_f(xcA.x) ? 0 : 1;
+                if (p1.x >= 0) n_invalid += finite_f(xcA.y) ? 0 : 1; else smA.y = qnan;
+                if (p2.x >= 0) n_invalid += finite_f(xcB.x) ? 0 : 1; else smB.x = qnan;
+                smB.y = qnan;
+            }
+            if (p0.y >= 0) {  // output rows
+                v2f sA = splat2(0.f), sB = splat2(0.f);
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    sA = sA + rA[J + j];
+                    sB = sB + rB[J + j];
+                }
+                // the reciprocal form is exact for odd W and powers of two only (even W have halfway cases among
+                // subnormal quotients that it misrounds: oracle/proofs/div_by_const.c); other W divide for real
+                constexpr bool recip_exact = (W & 1) || (W & (W - 1)) == 0;
+                v2f climA, climB;
+                if (recip_exact) {
+                    climA = div_const2(sA, Wf, yW);
+                    climB = div_const2(sB, Wf, yW);
+                } else {
+                    climA = (v2f){sA.x / Wf, sA.y / Wf};
+                    climB = (v2f){sB.x / Wf, sB.y / Wf};
+                }
+                // a NaN in the history (first days of the series, gaps) while the centre value is a number: nanmean
+                const bool slow = (!(climA.x == climA.x) && (write_clim || xcA.x == xcA.x)) ||
+                                  (!(climA.y == climA.y) && (write_clim || xcA.y == xcA.y)) ||
+                                  (!(climB.x == climB.x) && (write_clim || xcB.x == xcB.x)) ||
+                                  (!(climB.y == climB.y) && (write_clim || xcB.y == xcB.y));
+                if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                    int n[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int j = 0; j < W; ++j) {
+                        const float v[4] = {rA[J + j].x, rA[J + j].y, rB[J + j].x, rB[J + j].y};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (v[i] == v[i]) {
+                                acc[i] += v[i];
+                                ++n[i];
+                            }
+                    }
+                    // elements without a NaN term keep the fast result (identical: same sum, n == W)
+                    if (!(climA.x == climA.x)) climA.x = acc[0] / (float)n[0];
+                    if (!(climA.y == climA.y)) climA.y = acc[1] / (float)n[1];
+                    if (!(climB.x == climB.x)) climB.x = acc[2] / (float)n[2];
+                    if (!(climB.y == climB.y)) climB.y = acc[3] / (float)n[3];
+                }
+                const v2f aA = xcA - climA, aB = xcB - climB;
+                const rsrc_t ro = make_rsrc(out + (size_t)p0.y * C);
+                stb_f32(ro, voff, 0, write_clim ? climA.x : aA.x);
+                if (p1.x >= 0) stb_f32(ro, voff, rowb, write_clim ? climA.y : aA.y);
+                if (p2.x >= 0) stb_f32(ro, voff, 2 * rowb, write_clim ? climB.x : aB.x);
+                if (p3.x >= 0) stb_f32(ro, voff, 3 * rowb, write_clim ? climB.y : aB.y);
+                if (do_bins) {
+                    // np.digitize(a, edges) - 1 on the arange table (contract C4): the guess, biased down, is the
+                    // true bin or the one below (k_shift_classify checked the error bound); one comparison with
+                    // the edge above it -- recomputed with the table's own arithmetic -- settles which.  A NaN
+                    // guess clamps to 0 and is replaced by nb at the end.
+                    auto digit2 = [&](v2f a, int& k0, int& k1) {
+                        const v2f f = __builtin_elementwise_fma(a, splat2(inv_width), splat2(c0));
+                        v2f t;
+                        t.x = __builtin_amdgcn_fmed3f(__builtin_floorf(f.x), 0.0f, nbm1f);
+                        t.y = __builtin_amdgcn_fmed3f(__builtin_floorf(f.y), 0.0f, nbm1f);
+                        const v2f phi = t * splat2(e_delta);
+                        const v2f ehi = splat2(e_first) + phi;  // edges[t + 1]
+                        k0 = (int)t.x + (a.x >= ehi.x ? 1 : 0);
+                        k1 = (int)t.y + (a.y >= ehi.y ? 1 : 0);
+                        k0 = (a.x == a.x) ? k0 : nb;
+                        k1 = (a.y == a.y) ? k1 : nb;
+                    };
+                    int k0, k1, k2, k3;
+                    digit2(aA, k0, k1);
+                    digit2(aB, k2, k3);
+                    stb_u16(rbins, bin_lane, p0.z * 32, k0);
+                    if (p1.x >= 0) stb_u16(rbins, bin_lane, p1.z * 32, k1);
+                    if (p2.x >= 0) stb_u16(rbins, bin_lane, p2.z * 32, k2);
+                    if (p3.x >= 0) stb_u16(rbins, bin_lane, p3.z * 32, k3);
+                }
+            }
+        }
+        rA[J + W] = smA;  // year y joins the history
+        rB[J + W] = smB;
+        if (stage_next) stage_store((y + 1) & 1, nx);
+        __syncthreads();
+    };
+    for (int y = 0; y < n_cal; y += 2) {
+        one_year(y, std::integral_constant<int, 0>{});
+        if (y + 1 < n_cal) one_year(y + 1, std::integral_constant<int, 1>{});
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            rA[j] = rA[j + 2];
+            rB[j] = rB[j + 2];
+        }
+    }
+    if (invalid_count && active && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
+}
+
+struct ShiftArgs {
+    const float* x;
+    int64_t T, C;
+    const int4* year_plan;
+    int n_cal;
+    int W, S, write_clim;
+    const float* edges;
+    int nb;
+    int64_t T_out;
+    float* out;
+    uint16_t* bins;
+    uint8_t* mask;
+    int32_t* invalid_count;
+    const int* skip;
+};
+
+template <int D, int SCAP, bool SEXACT, int WCAP, bool RREG>
+static int launch_shifting(marex_ctx* ctx, const ShiftArgs& a) {
+    const int ncb = (int)((a.C + 255) / 256);
+    const int nchunks = (NDOY + D - 1) / D;
+    const size_t lds = ((RREG ? (size_t)0 : (size_t)D * WCAP * 256) + (a.bins ? (size_t)a.nb + 1 : 0)) * sizeof(float) + (size_t)a.n_cal * D * 16;
+    if (lds > 80 * 1024) return fail(ctx, -4, "marex_shifting_baseline_f32: window_year_baseline=%d needs more than 80 KiB of LDS", a.W);
+    auto kern = k_shifting<D, SCAP, SEXACT, WCAP, RREG>;
+    if (lds > 48 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(xcd_grid(ncb, nchunks)), dim3(256), lds, ctx->stream, a.x, (long)a.T, (long)a.C,
+                       a.year_plan, a.n_cal, a.W, a.S, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins,
+                       a.mask, a.invalid_count, ncb, nchunks, env_int("MAREX_SHIFT_ABLATE", 0), D == 4 ? a.skip : nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+template <int W>
+static void launch_shift_fast(marex_ctx* ctx, const ShiftArgs& a) {
+    const int ncg = (int)((a.C + 63) / 64);
+    hipLaunchKernelGGL(k_shift_fast<W>, dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C,
+                       a.year_plan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask,
+                       a.invalid_count, ncg, 23);
+}
+
+template <int D, int WCAP, bool RREG>
+static int dispatch_shifting_S(marex_ctx* ctx, const ShiftArgs& a) {
+    if (a.S == 21) return launch_shifting<D, 21, true, WCAP, RREG>(ctx, a);
+    return launch_shifting<D, 1, false, WCAP, RREG>(ctx, a);  // any other smoothing width: generic row loop
+}
+
+extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
+                                           const int32_t* year_plan, int n_cal_years, int W, int S,
+                                           int write_clim, const float* edges, int nb, int64_t T_out, float* out,
+                                           uint16_t* bins, uint8_t* mask, int32_t* invalid_count) {
+    if (!ctx) return -1;
+    if (!x || !year_plan || !out || T <= 0 || C <= 0 || n_cal_years <= 0)
+        return fail(ctx, -1, "marex_shifting_baseline_f32: null pointer or empty shape");
+    if (((uintptr_t)year_plan & 15) != 0) return fail(ctx, -1, "marex_shifting_baseline_f32: year_plan must be 16-byte aligned");
+    if (W < 1 || S < 1) return fail(ctx, -1, "marex_shifting_baseline_f32: W and S must be >= 1");
+    if (S > T) S = (int)T + 1;  // every window leaves the series: all-NaN smoothing either way
+    if (W > 64) return fail(ctx, -4, "marex_shifting_baseline_f32: window_year_baseline > 64 is not supported");
+    if (bins && (!edges || nb < 4 || nb > 65534 || T_out <= 0))
+        return fail(ctx, -1, "marex_shifting_baseline_f32: binning needs edges, T_out and 4 <= nb <= 65534");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ShiftArgs a{x, T, C, reinterpret_cast<const int4*>(year_plan), n_cal_years, W, S, write_clim,
+                edges, nb, T_out, out, bins, mask, invalid_count, nullptr};
+    // 4 dayofyears per workgroup (6 row loads per output) while the padded W-year LDS ring leaves room for two
+    // workgroups per CU, otherwise one dayofyear
+    const int forceD = env_int("MAREX_SHIFT_D", 0);
+    const int reg = env_int("MAREX_SHIFT_RING", 1);  // 1 (default): history in registers, 0: LDS ring
+    // regular chunks of the calendar go to k_shift_fast (S = 21, instantiated W, arange edge table)
+    const bool fast_w = W == 3 || W == 4 || W == 5 || W == 6 || W == 7 || W == 10 || W == 13 || W == 15;
+    const bool fast_cfg = env_int("MAREX_SHIFT_FAST", 1) != 0 && S == 21 && fast_w && forceD == 0 && T >= 24 &&
+                          T_out < (1 << 24) && C < (1 << 24) && env_int("MAREX_SHIFT_ABLATE", 0) == 0;
+    if (fast_cfg && !ctx->shift_info) HIP_TRY(ctx, hipMalloc((void**)&ctx->shift_info, SHIFT_INFO_WORDS * sizeof(int)));
+    LaunchTimer lt(ctx, MAREX_K_SHIFTING);  // one timed region: classify + fast kernel + general kernel
+    if (fast_cfg) {
+        hipLaunchKernelGGL(k_shift_classify, dim3(1), dim3(128), 0, ctx->stream, a.year_plan, n_cal_years, edges, nb,
+                           bins ? 1 : 0, 1, ctx->shift_info);
+        a.skip = ctx->shift_info;
+        switch (W) {
+            case 3: launch_shift_fast<3>(ctx, a); break;
+            case 4: launch_shift_fast<4>(ctx, a); break;
+            case 5: launch_shift_fast<5>(ctx, a); break;
+            case 6: launch_shift_fast<6>(ctx, a); break;
+            case 7: launch_shift_fast<7>(ctx, a); break;
+            case 10: launch_shift_fast<10>(ctx, a); break;
+            case 13: launch_shift_fast<13>(ctx, a); break;
+            default: launch_shift_fast<15>(ctx, a); break;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    if (W <= 8) {
+        if (reg) return forceD == 2 ? dispatch_shifting_S<2, 8, true>(ctx, a) : forceD == 8 ? dispatch_shifting_S<8, 8, true>(ctx, a) : dispatch_shifting_S<4, 8, true>(ctx, a);
+        return forceD == 1 ? dispatch_shifting_S<1, 8, false>(ctx, a) : dispatch_shifting_S<4, 8, false>(ctx, a);
+    }
+    if (W <= 16) {
+        if (reg) return forceD == 2 ? dispatch_shifting_S<2, 16, true>(ctx, a) : dispatch_shifting_S<4, 16, true>(ctx, a);
+        return forceD == 1 ? dispatch_shifting_S<1, 16, false>(ctx, a) : dispatch_shifting_S<4, 16, false>(ctx, a);
+    }
+    return dispatch_shifting_S<1, 64, false>(ctx, a);
+}
