@@ -51,7 +51,8 @@ enum {
     MAREX_K_EXACT = 7,
     MAREX_K_GLOBAL = 8,
     MAREX_K_STDNORM = 9,      /* day-of-year std, 30-day wrapped rolling RMS, anomaly / STD                 */
-    MAREX_K_COUNT = 10
+    MAREX_K_MORPH = 10,       /* tracker pre-processing: spatial closing + opening, temporal closing       */
+    MAREX_K_COUNT = 11
 };
 
 int marex_abi_version(void);
@@ -200,6 +201,17 @@ int marex_std_rolling_doy_f32(marex_ctx* ctx, const float* anom, int64_t T, int6
 /* part 2 (detect.py:2275-2278): out[t, c] = anom[t, c] / (std_roll[doy(t), c] > 1e-10 ? std_roll : NaN), float32 division */
 int marex_div_doy_f32(marex_ctx* ctx, const float* anom, const float* std_roll, const int32_t* doy_start,
                       const int32_t* doy_rows, int64_t T, int64_t C, float* out);
+
+/* Tracker pre-processing, gridded data (marEx/track.py:1520-1676): per timestep, pad the binary image by 2 R cells on
+ * every side (regional_mode 0: np.pad "wrap" in both dimensions, 1: "edge"), binary closing then binary opening with the
+ * disk x^2 + y^2 < R^2 + 1 (scipy.ndimage semantics, border_value 0), trim the padding, AND with the ocean mask.
+ * data / out: uint8 [T, ny, nx] (0 / 1); mask: uint8 [ny, nx].  R = 0: only the mask is applied. */
+int marex_fill_holes_u8(marex_ctx* ctx, const uint8_t* data, const uint8_t* mask, int64_t T, int ny, int nx, int R,
+                        int regional_mode, uint8_t* out);
+
+/* Temporal binary closing with T_fill + 1 consecutive steps (T_fill even), False outside the series
+ * (track.py:1694-1721); the caller follows it with marex_fill_holes_u8(R / 2) as the reference does (1724). */
+int marex_time_closing_u8(marex_ctx* ctx, const uint8_t* data, int64_t T, int64_t C, int T_fill, uint8_t* out);
 
 /* out[c, r] = in[r, c]  (thresholds [366, C] -> the reference's (cells, dayofyear) order) */
 int marex_transpose_f32(marex_ctx* ctx, const float* in, int64_t rows, int64_t cols, float* out);

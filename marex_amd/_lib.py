@@ -52,6 +52,8 @@ PROTOTYPES = {
     "marex_mask_ge_const_f32": (_i32, [_p, _p, _p, _i64, _i64, _p, _p]),
     "marex_std_rolling_doy_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _p, _p]),
     "marex_div_doy_f32": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _p]),
+    "marex_fill_holes_u8": (_i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
+    "marex_time_closing_u8": (_i32, [_p, _p, _i64, _i64, _i32, _p]),
 }
 
 KERNEL_IDS = {
@@ -65,6 +67,7 @@ KERNEL_IDS = {
     "exact": 7,
     "global": 8,
     "stdnorm": 9,
+    "morph": 10,
 }
 
 _lib: Optional[C.CDLL] = None

@@ -50,6 +50,8 @@ struct marex_ctx {
     size_t thr_scratch_bytes = 0;
     unsigned char* detrend_scratch = nullptr;  // device, partial sums / coefficients / means of the detrend reductions
     size_t detrend_scratch_bytes = 0;
+    unsigned char* morph_scratch = nullptr;  // device, two bit-packed padded images of the morphology passes
+    size_t morph_scratch_bytes = 0;
 };
 
 static inline int fail(marex_ctx* ctx, int code, const char* fmt, ...) {

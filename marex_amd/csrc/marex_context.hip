@@ -19,6 +19,7 @@ extern "C" int marex_destroy(marex_ctx* ctx) {
     if (ctx->shift_info) (void)hipFree(ctx->shift_info);
     if (ctx->thr_scratch) (void)hipFree(ctx->thr_scratch);
     if (ctx->detrend_scratch) (void)hipFree(ctx->detrend_scratch);
+    if (ctx->morph_scratch) (void)hipFree(ctx->morph_scratch);
     delete ctx;
     return 0;
 }

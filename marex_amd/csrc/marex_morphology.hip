@@ -1,0 +1,250 @@
+// marex_morphology.hip -- tracker pre-processing stage (first half): binary closing + opening of the
+// extreme mask with a disk (marEx/track.py:1520-1676, gridded branch) and the temporal closing (track.py:1678-1726).
+//
+// The image of one timestep is padded by 2R cells on every side (wrap = global grid, edge = regional mode), bit-packed
+// 64 cells per word, and the four morphological passes (dilate, erode | erode, dilate) run on the packed rows: one
+// thread per output word ORs, for every row offset dy of the disk, the row's word dilated horizontally by the disk's
+// half-width at dy (shifts across the word boundaries through the two neighbouring words).  Erosion is the dilation of
+// the complement with the outside set to 1 -- scipy's border_value = 0 for both operations, which the reference
+// inherits through dask_image, so the contamination that creeps 4R cells in from the padded border is reproduced too.
+#include "marex_common.hip.h"
+
+typedef unsigned long long u64;
+
+// padded packed layout: [T][Hp = ny + 4R][Wp = ceil((nx + 4R) / 64)] words; bit i of word w = cell x = 64 w + i of the
+// padded row; bits past the row end are kept 0.
+// one workgroup per padded row: the source row is resolved once (uniform), a wave packs 64 cells per ballot
+__global__ void __launch_bounds__(256)
+k_morph_pack(const unsigned char* __restrict__ data, long T, int ny, int nx, int R, int regional, int Hp, int Wp,
+             u64* __restrict__ packed) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nxp = nx + 4 * R;
+    const long rows = T * Hp;
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int yy = (int)(r % Hp);
+        const long t = r / Hp;
+        int y = yy - 2 * R;
+        if (regional) {  // np.pad mode="edge"
+            y = y < 0 ? 0 : (y >= ny ? ny - 1 : y);
+        } else {  // np.pad mode="wrap" (both dimensions, as the reference does)
+            y %= ny;
+            if (y < 0) y += ny;
+        }
+        const unsigned char* src = data + ((size_t)t * ny + y) * nx;
+        for (int w0 = wave; w0 < Wp; w0 += 4 * 8) {  // 8 byte loads in flight per lane before the ballots
+            unsigned char v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int xx = 64 * (w0 + 4 * u) + lane;
+                v[u] = 0;
+                if (w0 + 4 * u < Wp && xx < nxp) {
+                    int x = xx - 2 * R;
+                    if (regional) {
+                        x = x < 0 ? 0 : (x >= nx ? nx - 1 : x);
+                    } else {
+                        x %= nx;  // np.pad "wrap" repeats as often as needed (grids narrower than 2 R)
+                        if (x < 0) x += nx;
+                    }
+                    v[u] = src[x];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const u64 word = __ballot(v[u] != 0);
+                if (lane == 0 && w0 + 4 * u < Wp) packed[(size_t)r * Wp + w0 + 4 * u] = word;
+            }
+        }
+    }
+}
+
+// out = dilate(in) with the disk of radius R (half-width hw[|dy|] at row offset dy), the outside of the image
+// counting as `outside` (0 or ~0); invert: operate on the complement and complement the result (= erosion).
+__global__ void __launch_bounds__(256)
+k_morph_pass(const u64* __restrict__ in, u64* __restrict__ out, long T, int Hp, int Wp, int nxp, int R,
+             const int* __restrict__ hw, int invert) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long nwords = T * Hp * (long)Wp;
+    if (idx >= nwords) return;
+    const int w = (int)(idx % Wp);
+    const long ty = idx / Wp;
+    const int yy = (int)(ty % Hp);
+    const long t = ty / Hp;
+    const u64 flip = invert ? ~0ull : 0ull;      // complementing turns the stored 0 padding bits into the 1 outside
+    const u64 outside = flip;
+    const u64* img = in + (size_t)t * Hp * Wp;
+    u64 acc = 0;
+    for (int dy = -R; dy <= R; ++dy) {
+        const int y = yy + dy;
+        u64 L = outside, M = outside, Rw = outside;
+        if (y >= 0 && y < Hp) {
+            const u64* row = img + (size_t)y * Wp;
+            M = row[w] ^ flip;
+            if (w > 0) L = row[w - 1] ^ flip;
+            if (w + 1 < Wp) Rw = row[w + 1] ^ flip;
+        }
+        const int wd = hw[dy < 0 ? -dy : dy];
+        u64 d = M;
+        for (int k = 1; k <= wd; ++k) d |= (M >> k) | (Rw << (64 - k)) | (M << k) | (L >> (64 - k));
+        acc |= d;
+    }
+    acc ^= flip;
+    // keep the bits past the row end at 0
+    const int last_bits = nxp - 64 * (Wp - 1);
+    if (w == Wp - 1 && last_bits < 64) acc &= (1ull << last_bits) - 1ull;
+    out[idx] = acc;
+}
+
+// eight consecutive cells of a row per thread: 8 bits taken from one or two packed words, spread to bytes, ANDed with
+// the ocean mask, one 8-byte store
+__global__ void __launch_bounds__(256)
+k_morph_unpack(const u64* __restrict__ packed, const unsigned char* __restrict__ mask, long T, int ny, int nx, int R,
+               int Hp, int Wp, unsigned char* __restrict__ out) {
+    const int ng = (nx + 7) >> 3;  // groups of 8 cells per row
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * ny * (long)ng) return;
+    const int g = (int)(idx % ng);
+    const long ty = idx / ng;
+    const int y = (int)(ty % ny);
+    const long t = ty / ny;
+    const int x = g * 8, xx = x + 2 * R, yy = y + 2 * R;
+    const u64* row = packed + ((size_t)t * Hp + yy) * Wp;
+    const int w = xx >> 6, sh = xx & 63;
+    u64 bits = row[w] >> sh;
+    if (sh > 56 && w + 1 < Wp) bits |= row[w + 1] << (64 - sh);
+    const unsigned char* mrow = mask + (size_t)y * nx + x;
+    unsigned char* orow = out + ((size_t)t * ny + y) * nx + x;
+    if (x + 8 <= nx && (nx & 7) == 0) {
+        u64 spread = 0;  // byte i = bit i
+#pragma unroll
+        for (int i = 0; i < 8; ++i) spread |= ((bits >> i) & 1ull) << (8 * i);
+        const u64 m = *reinterpret_cast<const u64*>(mrow);
+        // mask bytes are 0 / 1
+        *reinterpret_cast<u64*>(orow) = spread & m;
+    } else {
+        for (int i = 0; i < 8 && x + i < nx; ++i) orow[i] = (((bits >> i) & 1ull) && mrow[i]) ? 1 : 0;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_mask_and(const unsigned char* __restrict__ data, const unsigned char* __restrict__ mask, long T, long C,
+           unsigned char* __restrict__ out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * C) return;
+    out[idx] = (data[idx] && mask[idx % C]) ? 1 : 0;
+}
+
+// temporal closing with a centred window of 2c+1 steps, False outside the series (track.py:1694-1718: kernel of
+// T_fill + 1 ones, T_fill even, padding of T_fill + 1 steps so that the border is never reached).
+// One thread = 16 consecutive cells x a block of timesteps; bytes are 0 / 1, so OR / AND act on whole 16-byte vectors.
+// The dilated rows of the block (+ c on either side) are kept in a small register ring.
+#define TC_MAXC 8
+#define TC_TBLOCK 32
+__device__ __forceinline__ uint4 or4(uint4 a, uint4 b) { return make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w); }
+__device__ __forceinline__ uint4 and4(uint4 a, uint4 b) { return make_uint4(a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w); }
+
+__global__ void __launch_bounds__(256)
+k_time_closing16(const unsigned char* __restrict__ data, long T, long C, int c, unsigned char* __restrict__ out) {
+    const long c16 = ((long)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (c16 >= C) return;
+    const long t0 = (long)blockIdx.y * TC_TBLOCK;
+    const long t1 = t0 + TC_TBLOCK < T ? t0 + TC_TBLOCK : T;
+    auto row = [&](long t) {
+        return (t >= 0 && t < T) ? *reinterpret_cast<const uint4*>(data + (size_t)t * C + c16) : make_uint4(0, 0, 0, 0);
+    };
+    auto dil = [&](long t) {  // OR of rows t-c .. t+c; zero outside the series (the padded part of the reference's array)
+        if (t < -(long)c - 1 || t > T + c) return make_uint4(0, 0, 0, 0);
+        uint4 d = row(t - c);
+        for (int i = -c + 1; i <= c; ++i) d = or4(d, row(t + i));
+        return d;
+    };
+    for (long t = t0; t < t1; ++t) {
+        uint4 e = dil(t - c);
+        for (int j = -c + 1; j <= c; ++j) e = and4(e, dil(t + j));
+        *reinterpret_cast<uint4*>(out + (size_t)t * C + c16) = e;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_time_closing(const unsigned char* __restrict__ data, long T, long C, int c, unsigned char* __restrict__ out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * C) return;
+    const long cell = idx % C, t = idx / C;
+    bool all = true;
+    for (int j = -c; j <= c && all; ++j) {  // erosion of ...
+        bool any = false;
+        for (int i = -c; i <= c; ++i) {      // ... the dilation
+            const long tt = t + j + i;
+            if (tt >= 0 && tt < T && data[(size_t)tt * C + cell]) any = true;
+        }
+        all = any;
+    }
+    out[idx] = all ? 1 : 0;
+}
+
+static int ensure_scratch(marex_ctx* ctx, size_t need) {
+    if (need > ctx->morph_scratch_bytes) {
+        if (ctx->morph_scratch) HIP_TRY(ctx, hipFree(ctx->morph_scratch));
+        ctx->morph_scratch = nullptr;
+        ctx->morph_scratch_bytes = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->morph_scratch, need));
+        ctx->morph_scratch_bytes = need;
+    }
+    return 0;
+}
+
+extern "C" int marex_fill_holes_u8(marex_ctx* ctx, const uint8_t* data, const uint8_t* mask, int64_t T, int ny, int nx,
+                                   int R, int regional_mode, uint8_t* out) {
+    if (!ctx) return -1;
+    if (!data || !mask || !out || T <= 0 || ny <= 0 || nx <= 0) return fail(ctx, -1, "marex_fill_holes_u8: null pointer or empty shape");
+    if (R < 0 || R > 63) return fail(ctx, -4, "marex_fill_holes_u8: R_fill must be in 0..63");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LaunchTimer lt(ctx, MAREX_K_MORPH);
+    const long C = (long)ny * nx;
+    if (R == 0) {  // no morphology, only the land mask (track.py:1620-1621, 1674)
+        hipLaunchKernelGGL(k_mask_and, dim3((unsigned)((T * C + 255) / 256)), dim3(256), 0, ctx->stream, data, mask, (long)T, C, out);
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    }
+    const int Hp = ny + 4 * R, nxp = nx + 4 * R, Wp = (nxp + 63) / 64;
+    const size_t words = (size_t)T * Hp * Wp;
+    const size_t need = 2 * words * sizeof(u64) + 64 * sizeof(int);
+    if (int rc = ensure_scratch(ctx, need)) return rc;
+    u64* a = reinterpret_cast<u64*>(ctx->morph_scratch);
+    u64* b = a + words;
+    int* hw_dev = reinterpret_cast<int*>(b + words);
+    int hw[64];
+    for (int dy = 0; dy <= R; ++dy) {  // se_kernel = x^2 + y^2 < R^2 + 1  (track.py:1613-1616)
+        int w = 0;
+        while ((w + 1) * (w + 1) + dy * dy < R * R + 1) ++w;
+        hw[dy] = w;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(hw_dev, hw, (R + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // hw lives on this stack frame
+    const unsigned gw = (unsigned)((words + 255) / 256);
+    hipLaunchKernelGGL(k_morph_pack, dim3((unsigned)((long)T * Hp < 1048576 ? (long)T * Hp : 1048576)), dim3(256), 0, ctx->stream, data, (long)T, ny, nx, R, regional_mode, Hp, Wp, a);
+    hipLaunchKernelGGL(k_morph_pass, dim3(gw), dim3(256), 0, ctx->stream, a, b, (long)T, Hp, Wp, nxp, R, hw_dev, 0);  // closing:
+    hipLaunchKernelGGL(k_morph_pass, dim3(gw), dim3(256), 0, ctx->stream, b, a, (long)T, Hp, Wp, nxp, R, hw_dev, 1);  //   dilate, erode
+    hipLaunchKernelGGL(k_morph_pass, dim3(gw), dim3(256), 0, ctx->stream, a, b, (long)T, Hp, Wp, nxp, R, hw_dev, 1);  // opening:
+    hipLaunchKernelGGL(k_morph_pass, dim3(gw), dim3(256), 0, ctx->stream, b, a, (long)T, Hp, Wp, nxp, R, hw_dev, 0);  //   erode, dilate
+    hipLaunchKernelGGL(k_morph_unpack, dim3((unsigned)((T * ny * (long)((nx + 7) / 8) + 255) / 256)), dim3(256), 0, ctx->stream, a,
+                       mask, (long)T, ny, nx, R, Hp, Wp, out);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int marex_time_closing_u8(marex_ctx* ctx, const uint8_t* data, int64_t T, int64_t C, int T_fill, uint8_t* out) {
+    if (!ctx) return -1;
+    if (!data || !out || T <= 0 || C <= 0) return fail(ctx, -1, "marex_time_closing_u8: null pointer or empty shape");
+    if (T_fill < 0 || (T_fill & 1)) return fail(ctx, -1, "marex_time_closing_u8: T_fill must be even and >= 0");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LaunchTimer lt(ctx, MAREX_K_MORPH);
+    if ((C & 15) == 0 && (((uintptr_t)data | (uintptr_t)out) & 15) == 0) {
+        dim3 grid((unsigned)((C / 16 + 255) / 256), (unsigned)((T + TC_TBLOCK - 1) / TC_TBLOCK));
+        hipLaunchKernelGGL(k_time_closing16, grid, dim3(256), 0, ctx->stream, data, (long)T, (long)C, T_fill / 2, out);
+    } else {
+        hipLaunchKernelGGL(k_time_closing, dim3((unsigned)((T * C + 255) / 256)), dim3(256), 0, ctx->stream, data, (long)T, (long)C,
+                           T_fill / 2, out);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

@@ -390,6 +390,32 @@ class HotPath:
         self.ctx.check(rc, "marex_div_doy_f32")
         return {"dat_stn": out, "STD": std_roll}
 
+    # ------------------------------------------------------------------ tracker pre-processing
+    def fill_holes(self, data_bin: torch.Tensor, mask: torch.Tensor, ny: int, nx: int, R_fill: int,
+                   regional_mode: bool = False, wsp: Optional[dict] = None, name: str = "filled") -> torch.Tensor:
+        """Binary closing + opening with a disk of radius ``R_fill`` per timestep, land masked (track.py:1520-1676).
+        ``data_bin``: uint8 ``[T, ny*nx]`` (0/1), ``mask``: uint8 ``[ny*nx]``."""
+        self._bind_stream()
+        T, Cn = data_bin.shape
+        assert Cn == ny * nx
+        out = self._buf(wsp, name, (T, Cn), torch.uint8, self.device)
+        rc = self.lib.marex_fill_holes_u8(self.ctx.handle, data_bin.data_ptr(), mask.data_ptr(), T, int(ny), int(nx),
+                                          int(R_fill), int(bool(regional_mode)), out.data_ptr())
+        self.ctx.check(rc, "marex_fill_holes_u8")
+        return out
+
+    def fill_time_gaps(self, data_bin: torch.Tensor, mask: torch.Tensor, ny: int, nx: int, R_fill: int, T_fill: int,
+                       regional_mode: bool = False, wsp: Optional[dict] = None) -> torch.Tensor:
+        """Temporal closing over ``T_fill + 1`` steps, then ``fill_holes(R_fill // 2)`` (track.py:1678-1726)."""
+        if T_fill == 0:
+            return data_bin
+        self._bind_stream()
+        T, Cn = data_bin.shape
+        tmp = self._buf(wsp, "time_closed", (T, Cn), torch.uint8, self.device)
+        rc = self.lib.marex_time_closing_u8(self.ctx.handle, data_bin.data_ptr(), T, Cn, int(T_fill), tmp.data_ptr())
+        self.ctx.check(rc, "marex_time_closing_u8")
+        return self.fill_holes(tmp, mask, ny, nx, int(R_fill) // 2, regional_mode, wsp=wsp, name="gap_filled")
+
     def hobday_thresholds_exact(self, anom: torch.Tensor, dcal: DeviceCalendar, percentile: float, wd: int,
                                 wsp: Optional[dict] = None) -> torch.Tensor:
         """``np.nanpercentile`` per (dayofyear window, cell), float32, layout ``[366, C]`` (detect.py:1921-1956)."""

@@ -1,0 +1,63 @@
+"""First half of the tracker's pre-processing stage on the device: the step that follows
+``preprocess_data`` in the reference pipeline and consumes ``extreme_events`` / ``mask`` while they are in HBM.
+
+Mirrors ``marEx.tracker.fill_holes`` (track.py:1520-1676, gridded branch) and ``marEx.tracker.fill_time_gaps``
+(track.py:1678-1726).  ``filter_small_objects`` / ``identify_objects`` (connected-component labelling) are not built yet.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .exceptions import ConfigurationError
+
+
+def _as_u8(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a.values if hasattr(a, "values") else a)).astype(np.uint8)
+
+
+def _check(data_bin, mask, R_fill, T_fill):
+    d = np.asarray(data_bin.values if hasattr(data_bin, "values") else data_bin)
+    m = np.asarray(mask.values if hasattr(mask, "values") else mask)
+    if d.ndim != 3 or m.shape != d.shape[1:]:
+        raise ConfigurationError("fill_holes / fill_time_gaps on the device need gridded data (time, y, x) and a (y, x) mask",
+                                 details=f"data {d.shape}, mask {m.shape}")
+    if T_fill % 2 != 0:  # track.py:704-709
+        raise ConfigurationError("T_fill must be even for temporal symmetry", details=f"Provided T_fill={T_fill} is odd")
+    if int(R_fill) < 0 or int(R_fill) > 63:
+        raise ConfigurationError("R_fill must be between 0 and 63 on the device path", details=f"R_fill={R_fill}")
+    return d, m
+
+
+def fill_holes(data_bin, mask, R_fill: int, regional_mode: bool = False, device: int = 0):
+    """Fill holes and remove specks: binary closing then opening with a disk of radius ``R_fill`` (track.py:1520-1676).
+    Returns a bool array (or DataArray with the input's labels) of the input's shape."""
+    import torch
+
+    from .detect import get_engine
+
+    d, m = _check(data_bin, mask, R_fill, 0)
+    eng = get_engine(device)
+    T, ny, nx = d.shape
+    x = torch.from_numpy(_as_u8(d).reshape(T, ny * nx)).to(eng.device)
+    mk = torch.from_numpy(_as_u8(m).reshape(-1)).to(eng.device)
+    out = eng.fill_holes(x, mk, ny, nx, int(R_fill), regional_mode)
+    eng.sync()
+    res = out.cpu().numpy().astype(bool).reshape(T, ny, nx)
+    return data_bin.copy(data=res) if hasattr(data_bin, "copy") and hasattr(data_bin, "dims") else res
+
+
+def fill_time_gaps(data_bin, mask, R_fill: int, T_fill: int = 2, regional_mode: bool = False, device: int = 0):
+    """Close gaps of up to ``T_fill`` steps in time, then ``fill_holes(R_fill // 2)`` (track.py:1678-1726)."""
+    import torch
+
+    from .detect import get_engine
+
+    d, m = _check(data_bin, mask, R_fill, T_fill)
+    eng = get_engine(device)
+    T, ny, nx = d.shape
+    x = torch.from_numpy(_as_u8(d).reshape(T, ny * nx)).to(eng.device)
+    mk = torch.from_numpy(_as_u8(m).reshape(-1)).to(eng.device)
+    out = eng.fill_time_gaps(x, mk, ny, nx, int(R_fill), int(T_fill), regional_mode)
+    eng.sync()
+    res = out.cpu().numpy().astype(bool).reshape(T, ny, nx)
+    return data_bin.copy(data=res) if hasattr(data_bin, "copy") and hasattr(data_bin, "dims") else res

@@ -588,3 +588,42 @@ def std_normalise(anom: np.ndarray, doy: np.ndarray, window: int = 30):
         safe = np.where(std_roll > np.float32(1e-10), std_roll, np.float32(np.nan)).astype(np.float32)
         dat_stn = (anom / safe[np.asarray(doy, dtype=np.int64) - 1]).astype(np.float32)
     return dat_stn, std_roll
+
+
+# --------------------------------------------------------------------------------------
+# tracker pre-processing (first half)              track.py:1520-1726
+# --------------------------------------------------------------------------------------
+def fill_holes(data_bin: np.ndarray, mask: np.ndarray, R_fill: int, regional_mode: bool = False) -> np.ndarray:
+    """``tracker.fill_holes`` on gridded data (marEx/track.py:1608-1676), literally: pad ``(y, x)`` by ``2 R`` with
+    ``np.pad`` (``wrap`` / ``edge``), ``binary_closing`` then ``binary_opening`` with the disk ``x^2 + y^2 < R^2 + 1``
+    applied per timestep, trim, ``where(mask, False)``.  The reference calls ``dask_image.ndmorph``, a chunked wrapper
+    of the very ``scipy.ndimage`` functions used here (border_value 0), so this oracle is the reference's own library.
+    ``data_bin``: bool ``[T, ny, nx]``; ``mask``: bool ``[ny, nx]``."""
+    from scipy import ndimage as ndi
+
+    data_bin = np.asarray(data_bin).astype(bool)
+    mask = np.asarray(mask).astype(bool)
+    R = int(R_fill)
+    if R > 0:
+        y, x = np.ogrid[-R:R + 1, -R:R + 1]
+        se = (x ** 2 + y ** 2) < (R ** 2) + 1
+        d = 2 * R
+        p = np.pad(data_bin, ((0, 0), (d, d), (d, d)), mode="edge" if regional_mode else "wrap")
+        p = ndi.binary_closing(p, structure=se[np.newaxis, :, :])
+        p = ndi.binary_opening(p, structure=se[np.newaxis, :, :])
+        data_bin = p[:, d:-d, d:-d]
+    return data_bin & mask[np.newaxis, :, :]
+
+
+def fill_time_gaps(data_bin: np.ndarray, mask: np.ndarray, R_fill: int, T_fill: int, regional_mode: bool = False) -> np.ndarray:
+    """``tracker.fill_time_gaps`` (track.py:1678-1726): pad time by ``T_fill + 1`` False steps, ``binary_closing`` with
+    ``T_fill + 1`` ones along time, trim, then ``fill_holes(R_fill // 2)``."""
+    from scipy import ndimage as ndi
+
+    data_bin = np.asarray(data_bin).astype(bool)
+    if T_fill == 0:
+        return data_bin
+    k = int(T_fill) + 1
+    p = np.pad(data_bin, ((k, k), (0, 0), (0, 0)), mode="constant", constant_values=False)
+    p = ndi.binary_closing(p, structure=np.ones(k, dtype=bool)[:, np.newaxis, np.newaxis])
+    return fill_holes(p[k:-k], mask, int(R_fill) // 2, regional_mode)
