@@ -213,6 +213,18 @@ int marex_fill_holes_u8(marex_ctx* ctx, const uint8_t* data, const uint8_t* mask
  * (track.py:1694-1721); the caller follows it with marex_fill_holes_u8(R / 2) as the reference does (1724). */
 int marex_time_closing_u8(marex_ctx* ctx, const uint8_t* data, int64_t T, int64_t C, int T_fill, uint8_t* out);
 
+/* Connected components of every timestep on its own (track.py:2013-2031 with time_connectivity = False): 8-connected in
+ * (y, x), periodic in x when wrap_x.  labels[i] = 1 + smallest linear index (into the whole [T, ny, nx] array) of the
+ * component of cell i, 0 = background -- unique across time like the reference's IDs, but numbered differently from
+ * scipy's scan order; areas[r] = number of cells of the component whose smallest index is r, 0 elsewhere. */
+int marex_label2d_i32(marex_ctx* ctx, const uint8_t* data, int64_t T, int ny, int nx, int wrap_x, int32_t* labels,
+                      int32_t* areas);
+
+/* out[i] = labels[i] > 0 && labels[i] != drop_label && areas[labels[i] - 1] >= area_threshold (track.py:1891-1903;
+ * drop_label = the reference's `object_ids_keep[0] = -1`, which removes the first object of the list) */
+int marex_filter_by_area_u8(marex_ctx* ctx, const int32_t* labels, const int32_t* areas, int64_t n,
+                            double area_threshold, int drop_label, uint8_t* out);
+
 /* out[c, r] = in[r, c]  (thresholds [366, C] -> the reference's (cells, dayofyear) order) */
 int marex_transpose_f32(marex_ctx* ctx, const float* in, int64_t rows, int64_t cols, float* out);
 

@@ -54,6 +54,8 @@ PROTOTYPES = {
     "marex_div_doy_f32": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _p]),
     "marex_fill_holes_u8": (_i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "marex_time_closing_u8": (_i32, [_p, _p, _i64, _i64, _i32, _p]),
+    "marex_label2d_i32": (_i32, [_p, _p, _i64, _i32, _i32, _i32, _p, _p]),
+    "marex_filter_by_area_u8": (_i32, [_p, _p, _p, _i64, _f64, _i32, _p]),
 }
 
 KERNEL_IDS = {

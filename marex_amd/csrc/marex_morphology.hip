@@ -248,3 +248,177 @@ extern "C" int marex_time_closing_u8(marex_ctx* ctx, const uint8_t* data, int64_
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Connected components per timestep (track.py:1912-2049 structured branch with time_connectivity = False: 8-connected
+// in (y, x), periodic in x unless regional) and the area filter of filter_small_objects (track.py:1755-1911).
+//
+// Label of a cell = 1 + the smallest linear index (over the whole [T, ny, nx] array) of its component, 0 = background:
+// concurrent union-find, one merge pass over the four "backward" neighbours (W, NW, N, NE), a compression pass, and a
+// flattening pass that also accumulates the areas at the roots.  Label VALUES differ from scipy's scan-order numbering; memberships and areas do not.
+// ------------------------------------------------------------------------------------------------
+// Union-find in the style of ECL-CC: a root is hooked under a smaller root with ONE compare-and-swap that only succeeds
+// while it is still a root; finds shorten the paths they walk with plain stores (path halving) -- safe because only
+// non-roots are rewritten (a non-root never becomes a root again, so it can never be the target of a hook) and the new
+// parent is always one of its ancestors.  Parents only decrease, so every loop terminates.
+__device__ __forceinline__ int uf_find(int* __restrict__ parent, int i) {
+    int p = parent[i];
+    while (p != i) {
+        const int g = parent[p];
+        if (g != p) parent[i] = g;
+        i = p;
+        p = g;
+    }
+    return i;
+}
+
+__device__ __forceinline__ void uf_union(int* __restrict__ parent, int a, int b) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    while (a != b) {
+        if (a < b) {
+            const int s = a;
+            a = b;
+            b = s;
+        }
+        const int old = atomicCAS(&parent[a], a, b);  // a > b: hook a under b if a is still a root
+        if (old == a) return;
+        a = uf_find(parent, old);  // a was hooked elsewhere meanwhile: continue from its new root
+        b = uf_find(parent, b);
+    }
+}
+
+// Initial parents: every True cell points at the first cell of its horizontal run inside its wave's 64 consecutive
+// cells (ballot + count-leading-zeros, no memory traffic) -- most "west" unions never have to happen.
+__global__ void __launch_bounds__(256)
+k_ccl_init(const unsigned char* __restrict__ data, long n, int nx, int* __restrict__ parent) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool on = i < n && data[i];
+    const bool row_start = i < n && (i % nx) == 0;
+    const unsigned long long on_m = __ballot(on);
+    // lane continues the run of lane-1: both set, same row
+    const unsigned long long cont = on_m & (on_m << 1) & ~__ballot(row_start);
+    if (i >= n) return;
+    if (!on) {
+        parent[i] = -1;
+        return;
+    }
+    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const unsigned long long breaks = ~cont & upto;  // bit 0 is always a break (cont has bit 0 clear)
+    const int start = 63 - __clzll((long long)breaks);
+    parent[i] = (int)(i - lane + start);
+}
+
+__global__ void __launch_bounds__(256)
+k_ccl_merge(const unsigned char* __restrict__ data, long T, int ny, int nx, int wrap_x, int* __restrict__ parent) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n = T * ny * (long)nx;
+    if (i >= n || !data[i]) return;
+    const int x = (int)(i % nx);
+    const int y = (int)((i / nx) % ny);
+    const long base = i - x;  // start of this row
+    // west: only where the in-wave run labelling could not see it (first lane of a wave) and across the periodic seam
+    if (x > 0) {
+        if ((threadIdx.x & 63) == 0 && data[i - 1]) uf_union(parent, (int)i, (int)(i - 1));
+    } else if (wrap_x && nx > 1 && data[base + nx - 1]) {
+        uf_union(parent, (int)i, (int)(base + nx - 1));
+    }
+    if (y > 0) {
+        const long up = base - nx;
+        if (data[up + x]) {
+            uf_union(parent, (int)i, (int)(up + x));  // N set: NW and NE hang on N through their own row
+        } else {
+            int xw = x - 1, xe = x + 1;
+            bool okw = true, oke = true;
+            if (xw < 0) {
+                okw = wrap_x && nx > 1;
+                xw += nx;
+            }
+            if (xe >= nx) {
+                oke = wrap_x && nx > 1;
+                xe -= nx;
+            }
+            if (okw && data[up + xw]) uf_union(parent, (int)i, (int)(up + xw));
+            if (oke && data[up + xe]) uf_union(parent, (int)i, (int)(up + xe));
+        }
+    }
+}
+
+// after all unions: point every cell straight at its root (plain stores are fine: nothing is merged any more)
+__global__ void __launch_bounds__(256)
+k_ccl_compress(long n, int* __restrict__ parent) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || parent[i] < 0) return;
+    int r = (int)i, p = parent[i];
+    while (p != r) {
+        r = p;
+        p = parent[r];
+    }
+    parent[i] = r;
+}
+
+// labels + areas; the lanes of a wave that share a root add their count with ONE atomic (a blob covering half the
+// ocean would otherwise serialise hundreds of thousands of atomics on one address)
+__global__ void __launch_bounds__(256)
+k_ccl_flatten(long n, const int* __restrict__ parent, int* __restrict__ labels, int* __restrict__ areas) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    int r = -1;
+    if (i < n) {
+        r = parent[i];
+        labels[i] = r < 0 ? 0 : r + 1;
+    }
+    unsigned long long todo = __ballot(r >= 0);
+    while (todo) {
+        const int lead = __ffsll((long long)todo) - 1;
+        const int rl = __shfl(r, lead, 64);
+        const unsigned long long same = __ballot(r == rl) & todo;
+        if ((int)(threadIdx.x & 63) == lead) atomicAdd(&areas[rl], __popcll(same));
+        todo &= ~same;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_ccl_filter(const int* __restrict__ labels, const int* __restrict__ areas, long n, double area_threshold, int drop_label,
+             unsigned char* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int l = labels[i];
+    out[i] = (l > 0 && l != drop_label && (double)areas[l - 1] >= area_threshold) ? 1 : 0;
+}
+
+extern "C" int marex_label2d_i32(marex_ctx* ctx, const uint8_t* data, int64_t T, int ny, int nx, int wrap_x,
+                                 int32_t* labels, int32_t* areas) {
+    if (!ctx) return -1;
+    if (!data || !labels || !areas || T <= 0 || ny <= 0 || nx <= 0) return fail(ctx, -1, "marex_label2d_i32: null pointer or empty shape");
+    const long n = (long)T * ny * nx;
+    if (n >= 2147483647L) return fail(ctx, -4, "marex_label2d_i32: more than 2^31 - 1 cells; label the series in time blocks");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LaunchTimer lt(ctx, MAREX_K_MORPH);
+    const unsigned g = (unsigned)((n + 255) / 256);
+    // `labels` doubles as the parent array during the merge; `areas` must start at zero
+    HIP_TRY(ctx, hipMemsetAsync(areas, 0, (size_t)n * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_ccl_init, dim3(g), dim3(256), 0, ctx->stream, data, n, nx, labels);
+    hipLaunchKernelGGL(k_ccl_merge, dim3(g), dim3(256), 0, ctx->stream, data, (long)T, ny, nx, wrap_x, labels);
+    // flatten in place is a race (a cell's parent may be overwritten by its label while another walks through it):
+    // write the labels to `areas`' sibling buffer instead -- here: a scratch copy of the parents
+    if (int rc = ensure_scratch(ctx, (size_t)n * sizeof(int))) return rc;
+    int* parent = reinterpret_cast<int*>(ctx->morph_scratch);
+    hipLaunchKernelGGL(k_ccl_compress, dim3(g), dim3(256), 0, ctx->stream, n, labels);
+    HIP_TRY(ctx, hipMemcpyAsync(parent, labels, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_ccl_flatten, dim3(g), dim3(256), 0, ctx->stream, n, parent, labels, areas);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int marex_filter_by_area_u8(marex_ctx* ctx, const int32_t* labels, const int32_t* areas, int64_t n,
+                                       double area_threshold, int drop_label, uint8_t* out) {
+    if (!ctx) return -1;
+    if (!labels || !areas || !out || n <= 0) return fail(ctx, -1, "marex_filter_by_area_u8: null pointer or empty shape");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LaunchTimer lt(ctx, MAREX_K_MORPH);
+    hipLaunchKernelGGL(k_ccl_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, labels, areas, (long)n,
+                       area_threshold, drop_label, out);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

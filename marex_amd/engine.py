@@ -416,6 +416,64 @@ class HotPath:
         self.ctx.check(rc, "marex_time_closing_u8")
         return self.fill_holes(tmp, mask, ny, nx, int(R_fill) // 2, regional_mode, wsp=wsp, name="gap_filled")
 
+    def label_objects_2d(self, data_bin: torch.Tensor, ny: int, nx: int, wrap_x: bool = True,
+                         wsp: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+        """Per-timestep 8-connected components (track.py:2013-2031): ``labels`` int32 ``[T, C]`` (1 + smallest linear
+        index of the component, 0 = background) and ``areas`` int32 ``[T, C]`` (cell count, stored at the root cell)."""
+        self._bind_stream()
+        T, Cn = data_bin.shape
+        labels = self._buf(wsp, "labels", (T, Cn), torch.int32, self.device)
+        areas = self._buf(wsp, "areas", (T, Cn), torch.int32, self.device)
+        rc = self.lib.marex_label2d_i32(self.ctx.handle, data_bin.data_ptr(), T, int(ny), int(nx), int(bool(wrap_x)),
+                                        labels.data_ptr(), areas.data_ptr())
+        self.ctx.check(rc, "marex_label2d_i32")
+        return {"labels": labels, "areas": areas}
+
+    def filter_small_objects(self, data_bin: torch.Tensor, ny: int, nx: int, area_filter_quartile: float = 0.5,
+                             area_filter_absolute: Optional[float] = None, regional_mode: bool = False,
+                             wsp: Optional[dict] = None) -> Dict[str, object]:
+        """Remove the objects smaller than a percentile (or an absolute number) of cells (track.py:1755-1911, gridded).
+        Series with more than 2^31 - 2 cells are labelled in time blocks (objects never span timesteps here)."""
+        T, Cn = data_bin.shape
+        tb = max(1, min(T, (2**31 - 2) // Cn))
+        blocks = []
+        for i, t0 in enumerate(range(0, T, tb)):
+            sub = None if wsp is None else wsp.setdefault(f"ccl{i}", {})
+            lab = self.label_objects_2d(data_bin[t0:t0 + tb], ny, nx, wrap_x=not regional_mode, wsp=sub)
+            blocks.append((t0, lab["labels"], lab["areas"]))
+        per_block = [a.reshape(-1)[a.reshape(-1) > 0] for _, _, a in blocks]  # ordered by (time, first cell)
+        obj_areas = torch.cat(per_block)
+        n_before = int(obj_areas.numel())
+        if n_before == 0:
+            raise ProcessingError("No objects found for area-based filtering")
+        if area_filter_absolute is not None:
+            thr = float(area_filter_absolute)
+        else:  # np.percentile(areas, 100 q), "linear": two order statistics from a device sort, NumPy's lerp on the host
+            srt = torch.sort(obj_areas).values
+            virt = (n_before - 1) * float(np.float64(area_filter_quartile * 100.0) / 100.0)
+            lo = int(np.floor(virt))
+            g = virt - lo
+            hi = min(lo + 1, n_before - 1)
+            a, b = float(srt[lo].item()), float(srt[hi].item())
+            thr = a + (b - a) * g if g < 0.5 else b - (b - a) * (1.0 - g)
+        out = self._buf(wsp, "filtered", tuple(data_bin.shape), torch.uint8, self.device)
+        dropped = False  # the reference's `object_ids_keep[0] = -1`: the first object of the whole list is never kept
+        n_after = int((obj_areas.to(torch.float64) >= thr).sum().item())
+        for (t0, labels, areas), pa in zip(blocks, per_block):
+            first = 0
+            if not dropped and pa.numel() > 0:
+                flat = areas.reshape(-1)
+                root = int(torch.nonzero(flat > 0)[0].item())
+                first = root + 1
+                if float(flat[root].item()) >= thr:
+                    n_after -= 1
+                dropped = True
+            rc = self.lib.marex_filter_by_area_u8(self.ctx.handle, labels.data_ptr(), areas.data_ptr(), labels.numel(), thr,
+                                                  first, out[t0:t0 + labels.shape[0]].data_ptr())
+            self.ctx.check(rc, "marex_filter_by_area_u8")
+        return {"filtered": out, "area_threshold": thr, "object_areas": obj_areas, "n_before": n_before, "n_after": n_after,
+                "labels": blocks[0][1] if len(blocks) == 1 else [b[1] for b in blocks]}
+
     def hobday_thresholds_exact(self, anom: torch.Tensor, dcal: DeviceCalendar, percentile: float, wd: int,
                                 wsp: Optional[dict] = None) -> torch.Tensor:
         """``np.nanpercentile`` per (dayofyear window, cell), float32, layout ``[366, C]`` (detect.py:1921-1956)."""

@@ -2,7 +2,8 @@
 ``preprocess_data`` in the reference pipeline and consumes ``extreme_events`` / ``mask`` while they are in HBM.
 
 Mirrors ``marEx.tracker.fill_holes`` (track.py:1520-1676, gridded branch) and ``marEx.tracker.fill_time_gaps``
-(track.py:1678-1726).  ``filter_small_objects`` / ``identify_objects`` (connected-component labelling) are not built yet.
+(track.py:1678-1726), ``marEx.tracker.identify_objects(time_connectivity=False)`` (track.py:1912-2049) and
+``marEx.tracker.filter_small_objects`` (track.py:1755-1911), all for gridded data.
 """
 from __future__ import annotations
 
@@ -61,3 +62,45 @@ def fill_time_gaps(data_bin, mask, R_fill: int, T_fill: int = 2, regional_mode: 
     eng.sync()
     res = out.cpu().numpy().astype(bool).reshape(T, ny, nx)
     return data_bin.copy(data=res) if hasattr(data_bin, "copy") and hasattr(data_bin, "dims") else res
+
+
+def identify_objects_2d(data_bin, regional_mode: bool = False, device: int = 0):
+    """Per-timestep 8-connected components, periodic in x unless ``regional_mode`` (track.py:2013-2031 with
+    ``time_connectivity=False``).  Returns ``(ID field int32 [T, ny, nx], number of objects)``; IDs are unique across
+    time, 0 = background; their numbering (1 + smallest linear index of the object) differs from the reference's."""
+    import torch
+
+    from .detect import get_engine
+
+    d = np.asarray(data_bin.values if hasattr(data_bin, "values") else data_bin)
+    if d.ndim != 3:
+        raise ConfigurationError("identify_objects_2d on the device needs gridded data (time, y, x)", details=f"data {d.shape}")
+    eng = get_engine(device)
+    T, ny, nx = d.shape
+    x = torch.from_numpy(_as_u8(d).reshape(T, ny * nx)).to(eng.device)
+    r = eng.label_objects_2d(x, ny, nx, wrap_x=not regional_mode)
+    eng.sync()
+    n = int((r["areas"] > 0).sum().item())
+    return r["labels"].cpu().numpy().reshape(T, ny, nx), n
+
+
+def filter_small_objects(data_bin, area_filter_quartile: float = 0.5, area_filter_absolute=None, regional_mode: bool = False,
+                         device: int = 0):
+    """Remove objects smaller than the ``area_filter_quartile`` percentile of all object areas (or an absolute number of
+    cells).  Returns ``(filtered, area_threshold, object_areas, N_objects_prefiltered, N_objects_filtered)`` like
+    track.py:1755-1911 (gridded branch: areas in cells)."""
+    import torch
+
+    from .detect import get_engine
+
+    d = np.asarray(data_bin.values if hasattr(data_bin, "values") else data_bin)
+    if d.ndim != 3:
+        raise ConfigurationError("filter_small_objects on the device needs gridded data (time, y, x)", details=f"data {d.shape}")
+    eng = get_engine(device)
+    T, ny, nx = d.shape
+    x = torch.from_numpy(_as_u8(d).reshape(T, ny * nx)).to(eng.device)
+    r = eng.filter_small_objects(x, ny, nx, area_filter_quartile, area_filter_absolute, regional_mode)
+    eng.sync()
+    res = r["filtered"].cpu().numpy().astype(bool).reshape(T, ny, nx)
+    out = data_bin.copy(data=res) if hasattr(data_bin, "copy") and hasattr(data_bin, "dims") else res
+    return out, r["area_threshold"], r["object_areas"].cpu().numpy(), r["n_before"], r["n_after"]

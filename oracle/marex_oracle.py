@@ -627,3 +627,64 @@ def fill_time_gaps(data_bin: np.ndarray, mask: np.ndarray, R_fill: int, T_fill: 
     p = np.pad(data_bin, ((k, k), (0, 0), (0, 0)), mode="constant", constant_values=False)
     p = ndi.binary_closing(p, structure=np.ones(k, dtype=bool)[:, np.newaxis, np.newaxis])
     return fill_holes(p[k:-k], mask, int(R_fill) // 2, regional_mode)
+
+
+def label_objects_2d(data_bin: np.ndarray, wrap_x: bool = True) -> np.ndarray:
+    """Connected components of every timestep on its own (track.py:2013-2031, ``time_connectivity=False``): 8-connected
+    in ``(y, x)``, periodic in ``x`` unless regional; ``scipy.ndimage.label`` per timestep plus a union over the seam.
+    Returns int64 labels, 0 = background, unique across time (numbering: scan order per timestep, offset by the number
+    of objects before -- the reference's dask_image numbering may differ; only memberships are contractual)."""
+    from scipy import ndimage as ndi
+
+    data_bin = np.asarray(data_bin).astype(bool)
+    T, ny, nx = data_bin.shape
+    out = np.zeros((T, ny, nx), dtype=np.int64)
+    offset = 0
+    for t in range(T):
+        lab, n = ndi.label(data_bin[t], structure=np.ones((3, 3), dtype=bool))
+        if wrap_x and n > 0 and nx > 1:
+            parent = np.arange(n + 1)
+
+            def find(a):
+                while parent[a] != a:
+                    parent[a] = parent[parent[a]]
+                    a = parent[a]
+                return a
+
+            left, right = lab[:, 0], lab[:, nx - 1]
+            for y in range(ny):
+                if left[y] == 0:
+                    continue
+                for yy in (y - 1, y, y + 1):
+                    if 0 <= yy < ny and right[yy] != 0:
+                        a, b = find(left[y]), find(right[yy])
+                        if a != b:
+                            parent[max(a, b)] = min(a, b)
+            roots = np.array([find(i) for i in range(n + 1)])
+            uniq, inv = np.unique(roots[1:], return_inverse=True)
+            remap = np.concatenate([[0], inv + 1])
+            lab = remap[lab]
+            n = uniq.size
+        out[t] = np.where(lab > 0, lab + offset, 0)
+        offset += n
+    return out
+
+
+def filter_small_objects(data_bin: np.ndarray, area_filter_quartile: float = 0.5, area_filter_absolute=None,
+                         regional_mode: bool = False):
+    """``tracker.filter_small_objects`` on gridded data (track.py:1873-1911): areas in cells per 2-D object, threshold =
+    ``np.percentile(areas, 100 q)`` (or the absolute one), keep ``area >= threshold`` -- and, as the reference's
+    ``object_ids_keep[0] = -1`` does, never keep the first object of the list (here: the object that contains the
+    first True cell in C order; the reference's list order comes from dask_image's labelling and is not pinned).
+    Returns ``(filtered bool, threshold, areas, n_before, n_after)``."""
+    data_bin = np.asarray(data_bin).astype(bool)
+    lab = label_objects_2d(data_bin, wrap_x=not regional_mode)
+    n = int(lab.max())
+    areas = np.bincount(lab.reshape(-1), minlength=n + 1)[1:].astype(np.float64)
+    if n == 0:
+        raise ValueError("No objects found for area-based filtering")
+    thr = float(area_filter_absolute) if area_filter_absolute is not None else float(np.percentile(areas, area_filter_quartile * 100.0))
+    keep = areas >= thr
+    keep[0] = False  # the first object of the list (label 1 = first True cell in scan order)
+    out = np.concatenate([[False], keep])[lab]
+    return out, thr, areas, n, int(keep.sum())

@@ -25,7 +25,10 @@ ws = {}
 
 def step():
     a = hot.fill_holes(ext, mask, ny, nx, 8, False, wsp=ws)
-    return hot.fill_time_gaps(a, mask, ny, nx, 8, 2, False, wsp=ws)
+    g = hot.fill_time_gaps(a, mask, ny, nx, 8, 2, False, wsp=ws)
+    if os.environ.get("MAREX_MEASURE_FILTER", "1") == "1":
+        return hot.filter_small_objects(g, ny, nx, 0.5, None, False, wsp=ws)["filtered"]
+    return g
 
 
 for _ in range(2):

@@ -58,3 +58,43 @@ def test_api_and_errors(hot):
         tp.fill_time_gaps(x, mask, 4, T_fill=3)
     with pytest.raises(Exception, match="gridded"):
         tp.fill_holes(x[:, 0], mask, 4)
+
+
+def _same_partition(a, b):
+    """Two label fields describe the same objects (labels may be numbered differently)."""
+    if not np.array_equal(a > 0, b > 0):
+        return False
+    fa, fb = a[a > 0], b[b > 0]
+    pairs = np.unique(np.stack([fa, fb], axis=1), axis=0)
+    return pairs.shape[0] == np.unique(fa).size == np.unique(fb).size
+
+
+@pytest.mark.parametrize("regional", [False, True])
+def test_connected_components_match_scipy(hot, regional):
+    rng = np.random.default_rng(11)
+    for (T, ny, nx, dens) in ((4, 33, 70, 0.3), (3, 64, 128, 0.55), (5, 9, 17, 0.5), (2, 1, 40, 0.5), (2, 40, 1, 0.5), (2, 5, 2, 0.6)):
+        x, _ = _blobs(rng, T, ny, nx, dens, land=0.0) if min(ny, nx) > 4 else (rng.random((T, ny, nx)) < dens, None)
+        x[:, :, 0] |= rng.random((T, ny)) < 0.3   # plenty of objects on the seam
+        x[:, :, -1] |= rng.random((T, ny)) < 0.3
+        exp = orc.label_objects_2d(x, wrap_x=not regional)
+        r = hot.label_objects_2d(torch.from_numpy(x.reshape(T, -1).astype(np.uint8)).to(hot.device), ny, nx, wrap_x=not regional)
+        hot.sync()
+        got = r["labels"].cpu().numpy().reshape(T, ny, nx)
+        assert _same_partition(got, exp), (regional, T, ny, nx)
+        areas = r["areas"].cpu().numpy().reshape(-1)
+        assert np.array_equal(np.sort(areas[areas > 0]), np.sort(np.bincount(exp.reshape(-1))[1:]))
+        assert int(exp.max()) == int((areas > 0).sum())
+
+
+@pytest.mark.parametrize("q,absolute,regional", [(0.5, None, False), (0.25, None, True), (0.9, None, False), (0.5, 12, False), (0.0, None, False)])
+def test_filter_small_objects_matches_the_oracle(hot, q, absolute, regional):
+    rng = np.random.default_rng(23)
+    T, ny, nx = 6, 48, 96
+    x, _ = _blobs(rng, T, ny, nx, 0.25, land=0.0)
+    exp, thr, areas, n0, n1 = orc.filter_small_objects(x, q, absolute, regional)
+    got, g_thr, g_areas, g0, g1 = tp.filter_small_objects(x, q, absolute, regional)
+    assert g_thr == thr and g0 == n0 and g1 == n1
+    assert np.array_equal(np.sort(g_areas), np.sort(areas))
+    assert np.array_equal(got, exp)
+    ids, n = tp.identify_objects_2d(x, regional)
+    assert n == n0 and _same_partition(ids, orc.label_objects_2d(x, wrap_x=not regional))
