@@ -225,6 +225,15 @@ int marex_label2d_i32(marex_ctx* ctx, const uint8_t* data, int64_t T, int ny, in
 int marex_filter_by_area_u8(marex_ctx* ctx, const int32_t* labels, const int32_t* areas, int64_t n,
                             double area_threshold, int drop_label, uint8_t* out);
 
+/* The same two stages on an unstructured mesh (track.py:1543-1606 and 1932-2004): nbr int32 [3, C], 0-based, -1 = no
+ * neighbour (the reference's `neighbours - 1`).  fill_holes: dilation by R = R sweeps of "OR over the cell and its listed
+ * neighbours"; closing with the land set True before the erosion, then opening, NO final land mask (as in the reference).
+ * label: components over the listed edges (undirected), land excluded; labels / areas as in marex_label2d_i32. */
+int marex_fill_holes_mesh_u8(marex_ctx* ctx, const uint8_t* data, const uint8_t* mask, const int32_t* nbr, int64_t T,
+                             int64_t C, int R, uint8_t* out);
+int marex_label_mesh_i32(marex_ctx* ctx, const uint8_t* data, const uint8_t* mask, const int32_t* nbr, int64_t T, int64_t C,
+                         int32_t* labels, int32_t* areas);
+
 /* out[c, r] = in[r, c]  (thresholds [366, C] -> the reference's (cells, dayofyear) order) */
 int marex_transpose_f32(marex_ctx* ctx, const float* in, int64_t rows, int64_t cols, float* out);
 

@@ -422,3 +422,104 @@ extern "C" int marex_filter_by_area_u8(marex_ctx* ctx, const int32_t* labels, co
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Unstructured meshes (track.py:1093-1117, 1543-1606, 1932-2004, 1776-1857): a cell's neighbourhood is itself plus up
+// to three edge neighbours (nbr[3][C], 0-based, -1 = none); dilation by R = R sweeps of "OR over the neighbourhood".
+// ------------------------------------------------------------------------------------------------
+// pre-operation applied to every value read by the FIRST sweep of a group (fuses the reference's elementwise steps):
+//   0: v                   1: !(v || land)      (b[:, ~mask] = True; ~b)
+//   2: v && !land          (~(~v | land))       3: !v
+__device__ __forceinline__ bool graph_pre(bool v, bool land, int pre) {
+    return pre == 0 ? v : pre == 1 ? !(v || land) : pre == 2 ? (v && !land) : !v;
+}
+
+__global__ void __launch_bounds__(256)
+k_graph_sweep(const unsigned char* __restrict__ in, const unsigned char* __restrict__ mask, const int* __restrict__ nbr,
+              long T, long C, int pre, int dilate, unsigned char* __restrict__ out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * C) return;
+    const long c = idx % C;
+    const unsigned char* row = in + (idx - c);
+    bool v = graph_pre(row[c] != 0, mask[c] == 0, pre);
+    if (dilate) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int n = nbr[(size_t)k * C + c];
+            if (n >= 0) v = v || graph_pre(row[n] != 0, mask[n] == 0, pre);
+        }
+    }
+    out[idx] = v ? 1 : 0;
+}
+
+extern "C" int marex_fill_holes_mesh_u8(marex_ctx* ctx, const uint8_t* data, const uint8_t* mask, const int32_t* nbr,
+                                        int64_t T, int64_t C, int R, uint8_t* out) {
+    if (!ctx) return -1;
+    if (!data || !mask || !nbr || !out || T <= 0 || C <= 0) return fail(ctx, -1, "marex_fill_holes_mesh_u8: null pointer or empty shape");
+    if (R < 0 || R > 1024) return fail(ctx, -4, "marex_fill_holes_mesh_u8: R_fill must be in 0..1024");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LaunchTimer lt(ctx, MAREX_K_MORPH);
+    const size_t n = (size_t)T * C;
+    if (int rc = ensure_scratch(ctx, 2 * n)) return rc;
+    unsigned char* bufs[2] = {ctx->morph_scratch, ctx->morph_scratch + n};
+    const unsigned g = (unsigned)((n + 255) / 256);
+    const unsigned char* cur = data;
+    int flip = 0;
+    // dilation | (land := True, complement) dilation | (complement, land := True, complement) dilation | complement, dilation
+    const int pres[4] = {0, 1, 2, 3};
+    for (int grp = 0; grp < 4; ++grp) {
+        const int sweeps = R > 0 ? R : 1;  // R = 0: only the elementwise step of the group
+        for (int s = 0; s < sweeps; ++s) {
+            const bool last = grp == 3 && s == sweeps - 1;
+            unsigned char* dst = last ? out : bufs[flip];
+            hipLaunchKernelGGL(k_graph_sweep, dim3(g), dim3(256), 0, ctx->stream, cur, mask, nbr, (long)T, (long)C,
+                               s == 0 ? pres[grp] : 0, R > 0 ? 1 : 0, dst);
+            cur = dst;
+            flip ^= 1;
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// connected components per timestep over the mesh edges, land excluded (track.py:1985, 1947-1981)
+__global__ void __launch_bounds__(256)
+k_mesh_ccl_init(const unsigned char* __restrict__ data, const unsigned char* __restrict__ mask, long T, long C,
+                int* __restrict__ parent) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < T * C) parent[i] = (data[i] && mask[i % C]) ? (int)i : -1;
+}
+
+__global__ void __launch_bounds__(256)
+k_mesh_ccl_merge(const int* __restrict__ nbr, long T, long C, int* __restrict__ parent) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * C || parent[i] < 0) return;
+    const long c = i % C, base = i - c;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int n = nbr[(size_t)k * C + c];
+        // an edge is an undirected link whichever end lists it (connected_components(directed=False), track.py:1979)
+        if (n >= 0 && n != c && parent[base + n] >= 0) uf_union(parent, (int)i, (int)(base + n));
+    }
+}
+
+extern "C" int marex_label_mesh_i32(marex_ctx* ctx, const uint8_t* data, const uint8_t* mask, const int32_t* nbr, int64_t T,
+                                    int64_t C, int32_t* labels, int32_t* areas) {
+    if (!ctx) return -1;
+    if (!data || !mask || !nbr || !labels || !areas || T <= 0 || C <= 0) return fail(ctx, -1, "marex_label_mesh_i32: null pointer or empty shape");
+    const long n = (long)T * C;
+    if (n >= 2147483647L) return fail(ctx, -4, "marex_label_mesh_i32: more than 2^31 - 1 cells; label the series in time blocks");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LaunchTimer lt(ctx, MAREX_K_MORPH);
+    const unsigned g = (unsigned)((n + 255) / 256);
+    HIP_TRY(ctx, hipMemsetAsync(areas, 0, (size_t)n * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_mesh_ccl_init, dim3(g), dim3(256), 0, ctx->stream, data, mask, (long)T, (long)C, labels);
+    hipLaunchKernelGGL(k_mesh_ccl_merge, dim3(g), dim3(256), 0, ctx->stream, nbr, (long)T, (long)C, labels);
+    hipLaunchKernelGGL(k_ccl_compress, dim3(g), dim3(256), 0, ctx->stream, n, labels);
+    if (int rc = ensure_scratch(ctx, (size_t)n * sizeof(int))) return rc;
+    int* parent = reinterpret_cast<int*>(ctx->morph_scratch);
+    HIP_TRY(ctx, hipMemcpyAsync(parent, labels, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_ccl_flatten, dim3(g), dim3(256), 0, ctx->stream, n, parent, labels, areas);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

@@ -474,6 +474,52 @@ class HotPath:
         return {"filtered": out, "area_threshold": thr, "object_areas": obj_areas, "n_before": n_before, "n_after": n_after,
                 "labels": blocks[0][1] if len(blocks) == 1 else [b[1] for b in blocks]}
 
+    def fill_holes_mesh(self, data_bin: torch.Tensor, mask: torch.Tensor, nbr: torch.Tensor, R_fill: int,
+                        wsp: Optional[dict] = None) -> torch.Tensor:
+        """``fill_holes`` on an unstructured mesh (track.py:1543-1606): ``nbr`` int32 ``[3, C]``, 0-based, -1 = none."""
+        self._bind_stream()
+        T, Cn = data_bin.shape
+        out = self._buf(wsp, "filled_mesh", (T, Cn), torch.uint8, self.device)
+        rc = self.lib.marex_fill_holes_mesh_u8(self.ctx.handle, data_bin.data_ptr(), mask.data_ptr(), nbr.data_ptr(), T, Cn,
+                                               int(R_fill), out.data_ptr())
+        self.ctx.check(rc, "marex_fill_holes_mesh_u8")
+        return out
+
+    def filter_small_objects_mesh(self, data_bin: torch.Tensor, mask: torch.Tensor, nbr: torch.Tensor,
+                                  area_filter_quartile: float = 0.5, area_filter_absolute: Optional[float] = None,
+                                  wsp: Optional[dict] = None) -> Dict[str, object]:
+        """``filter_small_objects`` on an unstructured mesh (track.py:1776-1857): sizes in cells, percentile over the
+        clusters larger than 50 (5) cells, keep STRICTLY larger than the threshold."""
+        self._bind_stream()
+        T, Cn = data_bin.shape
+        labels = self._buf(wsp, "labels_mesh", (T, Cn), torch.int32, self.device)
+        areas = self._buf(wsp, "areas_mesh", (T, Cn), torch.int32, self.device)
+        rc = self.lib.marex_label_mesh_i32(self.ctx.handle, data_bin.data_ptr(), mask.data_ptr(), nbr.data_ptr(), T, Cn,
+                                           labels.data_ptr(), areas.data_ptr())
+        self.ctx.check(rc, "marex_label_mesh_i32")
+        flat = areas.reshape(-1)
+        big = flat[flat > (5 if area_filter_absolute is not None else 50)]
+        n_before = int(big.numel())
+        if n_before == 0:
+            raise ProcessingError("No objects found for area-based filtering")
+        if area_filter_absolute is not None:
+            thr = float(area_filter_absolute)
+        else:
+            srt = torch.sort(big).values
+            virt = (n_before - 1) * float(np.float64(area_filter_quartile * 100) / 100.0)
+            lo = int(np.floor(virt))
+            g = virt - lo
+            hi = min(lo + 1, n_before - 1)
+            a, b = float(srt[lo].item()), float(srt[hi].item())
+            thr = a + (b - a) * g if g < 0.5 else b - (b - a) * (1.0 - g)
+        out = self._buf(wsp, "filtered_mesh", (T, Cn), torch.uint8, self.device)
+        # strict ">" : areas are integers, so "> thr" == ">= floor(thr) + 1"
+        rc = self.lib.marex_filter_by_area_u8(self.ctx.handle, labels.data_ptr(), areas.data_ptr(), labels.numel(),
+                                              float(np.floor(thr) + 1.0), 0, out.data_ptr())
+        self.ctx.check(rc, "marex_filter_by_area_u8")
+        return {"filtered": out, "area_threshold": thr, "object_areas": big, "n_before": n_before,
+                "n_after": int((big.to(torch.float64) > thr).sum().item()), "labels": labels}
+
     def hobday_thresholds_exact(self, anom: torch.Tensor, dcal: DeviceCalendar, percentile: float, wd: int,
                                 wsp: Optional[dict] = None) -> torch.Tensor:
         """``np.nanpercentile`` per (dayofyear window, cell), float32, layout ``[366, C]`` (detect.py:1921-1956)."""

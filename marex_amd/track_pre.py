@@ -3,7 +3,8 @@
 
 Mirrors ``marEx.tracker.fill_holes`` (track.py:1520-1676, gridded branch) and ``marEx.tracker.fill_time_gaps``
 (track.py:1678-1726), ``marEx.tracker.identify_objects(time_connectivity=False)`` (track.py:1912-2049) and
-``marEx.tracker.filter_small_objects`` (track.py:1755-1911), all for gridded data.
+``marEx.tracker.filter_small_objects`` (track.py:1755-1911), for gridded data and -- given ``neighbours`` -- for
+unstructured meshes.
 """
 from __future__ import annotations
 
@@ -16,10 +17,15 @@ def _as_u8(a) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a.values if hasattr(a, "values") else a)).astype(np.uint8)
 
 
-def _check(data_bin, mask, R_fill, T_fill):
+def _check(data_bin, mask, R_fill, T_fill, neighbours=None):
     d = np.asarray(data_bin.values if hasattr(data_bin, "values") else data_bin)
     m = np.asarray(mask.values if hasattr(mask, "values") else mask)
-    if d.ndim != 3 or m.shape != d.shape[1:]:
+    if neighbours is not None:
+        nb = np.asarray(neighbours.values if hasattr(neighbours, "values") else neighbours)
+        if d.ndim != 2 or m.shape != d.shape[1:] or nb.shape != (3, d.shape[1]):  # track.py:1063-1090
+            raise ConfigurationError("Invalid neighbour array shape for unstructured grid",
+                                     details=f"data {d.shape}, mask {m.shape}, neighbours {nb.shape}; expected (time, ncells), (ncells), (3, ncells)")
+    elif d.ndim != 3 or m.shape != d.shape[1:]:
         raise ConfigurationError("fill_holes / fill_time_gaps on the device need gridded data (time, y, x) and a (y, x) mask",
                                  details=f"data {d.shape}, mask {m.shape}")
     if T_fill % 2 != 0:  # track.py:704-709
@@ -29,15 +35,32 @@ def _check(data_bin, mask, R_fill, T_fill):
     return d, m
 
 
-def fill_holes(data_bin, mask, R_fill: int, regional_mode: bool = False, device: int = 0):
-    """Fill holes and remove specks: binary closing then opening with a disk of radius ``R_fill`` (track.py:1520-1676).
+def _nbr0(neighbours) -> np.ndarray:
+    """The reference's ``neighbours.astype(np.int32) - 1`` (track.py:1060): 1-based input, 0 = no neighbour."""
+    nb = np.asarray(neighbours.values if hasattr(neighbours, "values") else neighbours)
+    return np.ascontiguousarray(nb.astype(np.int32) - 1)
+
+
+def _wrap(data_bin, res):
+    return data_bin.copy(data=res) if hasattr(data_bin, "copy") and hasattr(data_bin, "dims") else res
+
+
+def fill_holes(data_bin, mask, R_fill: int, regional_mode: bool = False, neighbours=None, device: int = 0):
+    """Fill holes and remove specks: binary closing then opening with a disk of radius ``R_fill`` (track.py:1520-1676);
+    with ``neighbours`` (1-based ``[3, ncells]``) the unstructured-mesh form on ``(time, ncells)`` data.
     Returns a bool array (or DataArray with the input's labels) of the input's shape."""
     import torch
 
     from .detect import get_engine
 
-    d, m = _check(data_bin, mask, R_fill, 0)
+    d, m = _check(data_bin, mask, R_fill, 0, neighbours)
     eng = get_engine(device)
+    if neighbours is not None:
+        x = torch.from_numpy(_as_u8(d)).to(eng.device)
+        out = eng.fill_holes_mesh(x, torch.from_numpy(_as_u8(m)).to(eng.device), torch.from_numpy(_nbr0(neighbours)).to(eng.device),
+                                  int(R_fill))
+        eng.sync()
+        return _wrap(data_bin, out.cpu().numpy().astype(bool))
     T, ny, nx = d.shape
     x = torch.from_numpy(_as_u8(d).reshape(T, ny * nx)).to(eng.device)
     mk = torch.from_numpy(_as_u8(m).reshape(-1)).to(eng.device)
@@ -47,14 +70,26 @@ def fill_holes(data_bin, mask, R_fill: int, regional_mode: bool = False, device:
     return data_bin.copy(data=res) if hasattr(data_bin, "copy") and hasattr(data_bin, "dims") else res
 
 
-def fill_time_gaps(data_bin, mask, R_fill: int, T_fill: int = 2, regional_mode: bool = False, device: int = 0):
+def fill_time_gaps(data_bin, mask, R_fill: int, T_fill: int = 2, regional_mode: bool = False, neighbours=None, device: int = 0):
     """Close gaps of up to ``T_fill`` steps in time, then ``fill_holes(R_fill // 2)`` (track.py:1678-1726)."""
     import torch
 
     from .detect import get_engine
 
-    d, m = _check(data_bin, mask, R_fill, T_fill)
+    d, m = _check(data_bin, mask, R_fill, T_fill, neighbours)
     eng = get_engine(device)
+    if neighbours is not None:
+        if T_fill == 0:
+            return data_bin
+        x = torch.from_numpy(_as_u8(d)).to(eng.device)
+        tmp = torch.empty_like(x)
+        eng._bind_stream()
+        eng.ctx.check(eng.lib.marex_time_closing_u8(eng.ctx.handle, x.data_ptr(), x.shape[0], x.shape[1], int(T_fill), tmp.data_ptr()),
+                      "marex_time_closing_u8")
+        out = eng.fill_holes_mesh(tmp, torch.from_numpy(_as_u8(m)).to(eng.device), torch.from_numpy(_nbr0(neighbours)).to(eng.device),
+                                  int(R_fill) // 2)
+        eng.sync()
+        return _wrap(data_bin, out.cpu().numpy().astype(bool))
     T, ny, nx = d.shape
     x = torch.from_numpy(_as_u8(d).reshape(T, ny * nx)).to(eng.device)
     mk = torch.from_numpy(_as_u8(m).reshape(-1)).to(eng.device)
@@ -85,7 +120,7 @@ def identify_objects_2d(data_bin, regional_mode: bool = False, device: int = 0):
 
 
 def filter_small_objects(data_bin, area_filter_quartile: float = 0.5, area_filter_absolute=None, regional_mode: bool = False,
-                         device: int = 0):
+                         mask=None, neighbours=None, device: int = 0):
     """Remove objects smaller than the ``area_filter_quartile`` percentile of all object areas (or an absolute number of
     cells).  Returns ``(filtered, area_threshold, object_areas, N_objects_prefiltered, N_objects_filtered)`` like
     track.py:1755-1911 (gridded branch: areas in cells)."""
@@ -94,6 +129,14 @@ def filter_small_objects(data_bin, area_filter_quartile: float = 0.5, area_filte
     from .detect import get_engine
 
     d = np.asarray(data_bin.values if hasattr(data_bin, "values") else data_bin)
+    if neighbours is not None:  # unstructured mesh: sizes in cells, clusters > 50 (5) cells enter the percentile, keep "> threshold"
+        d, m = _check(data_bin, mask, 0, 0, neighbours)
+        eng = get_engine(device)
+        r = eng.filter_small_objects_mesh(torch.from_numpy(_as_u8(d)).to(eng.device), torch.from_numpy(_as_u8(m)).to(eng.device),
+                                          torch.from_numpy(_nbr0(neighbours)).to(eng.device), area_filter_quartile, area_filter_absolute)
+        eng.sync()
+        return (_wrap(data_bin, r["filtered"].cpu().numpy().astype(bool)), r["area_threshold"], r["object_areas"].cpu().numpy(),
+                r["n_before"], r["n_after"])
     if d.ndim != 3:
         raise ConfigurationError("filter_small_objects on the device needs gridded data (time, y, x)", details=f"data {d.shape}")
     eng = get_engine(device)

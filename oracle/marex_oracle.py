@@ -688,3 +688,76 @@ def filter_small_objects(data_bin: np.ndarray, area_filter_quartile: float = 0.5
     keep[0] = False  # the first object of the list (label 1 = first True cell in scan order)
     out = np.concatenate([[False], keep])[lab]
     return out, thr, areas, n, int(keep.sum())
+
+
+def _mesh_dilation_matrix(neighbours_int: np.ndarray):
+    """``tracker._build_sparse_dilation_matrix`` (track.py:1093-1117): (cell, listed neighbour) entries plus identity."""
+    from scipy.sparse import coo_matrix, csr_matrix, eye
+
+    nb = np.asarray(neighbours_int)
+    n = nb.shape[1]
+    rows = np.repeat(np.arange(n), 3)
+    cols = nb.T.flatten()
+    ok = cols >= 0
+    m = csr_matrix(coo_matrix((np.ones(int(ok.sum()), dtype=bool), (rows[ok], cols[ok])), shape=(n, n)))
+    return m + eye(n, dtype=bool, format="csr")
+
+
+def fill_holes_mesh(data_bin: np.ndarray, mask: np.ndarray, neighbours_int: np.ndarray, R_fill: int) -> np.ndarray:
+    """``tracker.fill_holes`` on an unstructured mesh (track.py:1543-1606; ``sparse_bool_power`` = ``R`` boolean products
+    with the dilation matrix).  ``data_bin`` bool ``[T, C]``, ``neighbours_int`` int ``[3, C]`` 0-based, -1 = none.  The
+    reference does not re-apply the land mask at the end of this branch."""
+    m = _mesh_dilation_matrix(neighbours_int).astype(np.int32)
+    mask = np.asarray(mask).astype(bool)
+
+    def power(b):
+        v = b.T.astype(np.int32)  # [C, T]
+        for _ in range(int(R_fill)):
+            v = (m @ v > 0).astype(np.int32)
+        return v.T.astype(bool)
+
+    b = power(np.asarray(data_bin).astype(bool))
+    b[:, ~mask] = True
+    b = ~power(~b)
+    b[:, ~mask] = True
+    b = ~power(~b)
+    return power(b)
+
+
+def label_objects_mesh(data_bin: np.ndarray, mask: np.ndarray, neighbours_int: np.ndarray) -> np.ndarray:
+    """Connected components per timestep over the mesh edges (track.py:1947-1985), land excluded.  int64 labels, 0 =
+    background, made unique across time here (the reference restarts at 1 in every slice)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+
+    d = np.asarray(data_bin).astype(bool) & np.asarray(mask).astype(bool)[None, :]
+    nb = np.asarray(neighbours_int)
+    T, C = d.shape
+    out = np.zeros((T, C), dtype=np.int64)
+    offset = 0
+    for t in range(T):
+        k, c = np.nonzero((nb != -1) & d[t][np.where(nb >= 0, nb, 0)] & d[t][None, :])
+        g = coo_matrix((np.ones(k.size, dtype=np.int8), (nb[k, c], c)), shape=(C, C))
+        n, lab = connected_components(g, directed=False)
+        ids = np.unique(lab[d[t]])
+        remap = np.zeros(n, dtype=np.int64)
+        remap[ids] = np.arange(1, ids.size + 1)
+        out[t] = np.where(d[t], remap[lab] + offset, 0)
+        offset += ids.size
+    return out
+
+
+def filter_small_objects_mesh(data_bin, mask, neighbours_int, area_filter_quartile: float = 0.5, area_filter_absolute=None):
+    """``tracker.filter_small_objects`` on an unstructured mesh (track.py:1776-1857): sizes in cells per (timestep, cluster);
+    the percentile is taken over the clusters larger than 50 cells (5 with an absolute threshold); clusters are kept when
+    STRICTLY larger than the threshold.  Returns ``(filtered, threshold, sizes of the clusters that entered the
+    percentile, their number, number kept among them)``."""
+    lab = label_objects_mesh(data_bin, mask, neighbours_int)
+    n = int(lab.max())
+    sizes = np.bincount(lab.reshape(-1), minlength=n + 1)[1:]
+    big = sizes[sizes > (5 if area_filter_absolute is not None else 50)].astype(np.float64)
+    if big.size == 0:
+        raise ValueError("No objects found for area-based filtering")
+    thr = float(area_filter_absolute) if area_filter_absolute is not None else float(np.percentile(big, area_filter_quartile * 100))
+    keep = np.concatenate([[False], sizes > thr])
+    return keep[lab], thr, big, int(big.size), int((big > thr).sum())

@@ -98,3 +98,67 @@ def test_filter_small_objects_matches_the_oracle(hot, q, absolute, regional):
     assert np.array_equal(got, exp)
     ids, n = tp.identify_objects_2d(x, regional)
     assert n == n0 and _same_partition(ids, orc.label_objects_2d(x, wrap_x=not regional))
+
+
+def _tri_mesh(rng, C):
+    """A random 3-regular-ish neighbour table: cells on a ring with one random chord each, some neighbours missing,
+    some listed from one end only (the reference treats listed pairs as undirected for clustering)."""
+    nb = np.full((3, C), -1, dtype=np.int32)
+    nb[0] = (np.arange(C) + 1) % C
+    nb[1] = (np.arange(C) - 1) % C
+    nb[2] = rng.integers(0, C, C)
+    nb[2][rng.random(C) < 0.2] = -1
+    nb[1][rng.random(C) < 0.05] = -1
+    return nb
+
+
+@pytest.mark.parametrize("R", [0, 1, 3, 6])
+def test_mesh_fill_holes_matches_the_sparse_matrix_form(hot, R):
+    rng = np.random.default_rng(40 + R)
+    T, C = 7, 613
+    nb = _tri_mesh(rng, C)
+    x = rng.random((T, C)) < 0.2
+    mask = rng.random(C) > 0.15
+    x &= mask
+    exp = orc.fill_holes_mesh(x, mask, nb, R)
+    got = hot.fill_holes_mesh(torch.from_numpy(x.astype(np.uint8)).to(hot.device), torch.from_numpy(mask.astype(np.uint8)).to(hot.device),
+                              torch.from_numpy(nb).to(hot.device), R)
+    hot.sync()
+    assert np.array_equal(got.cpu().numpy().astype(bool), exp)
+
+
+@pytest.mark.parametrize("q,absolute", [(0.5, None), (0.2, None), (0.5, 30)])
+def test_mesh_components_and_filter_match_scipy(hot, q, absolute):
+    rng = np.random.default_rng(77)
+    T, C = 5, 4000
+    nb = _tri_mesh(rng, C)
+    nb[2] = np.where(rng.random(C) < 0.7, -1, nb[2])  # mostly a ring: long clusters
+    x = rng.random((T, C)) < 0.93
+    mask = rng.random(C) > 0.02
+    exp, thr, big, n0, n1 = orc.filter_small_objects_mesh(x, mask, nb, q, absolute)
+    r = hot.filter_small_objects_mesh(torch.from_numpy(x.astype(np.uint8)).to(hot.device),
+                                      torch.from_numpy(mask.astype(np.uint8)).to(hot.device), torch.from_numpy(nb).to(hot.device),
+                                      q, absolute)
+    hot.sync()
+    assert r["area_threshold"] == thr and r["n_before"] == n0 and r["n_after"] == n1
+    assert np.array_equal(np.sort(r["object_areas"].cpu().numpy()), np.sort(big))
+    assert np.array_equal(r["filtered"].cpu().numpy().astype(bool), exp)
+    assert _same_partition(r["labels"].cpu().numpy(), orc.label_objects_mesh(x, mask, nb))
+
+
+def test_mesh_api(hot):
+    rng = np.random.default_rng(5)
+    T, C = 9, 900
+    nb0 = _tri_mesh(rng, C)
+    nb1 = nb0 + 1  # the reference's 1-based table, 0 = none
+    mask = rng.random(C) > 0.1
+    x = (rng.random((T, C)) < 0.3) & mask
+    a = tp.fill_holes(x, mask, 2, neighbours=nb1)
+    assert np.array_equal(a, orc.fill_holes_mesh(x, mask, nb0, 2))
+    b = tp.fill_time_gaps(a, mask, 4, T_fill=2, neighbours=nb1)
+    from scipy import ndimage as ndi
+    closed = ndi.binary_closing(np.pad(a, ((3, 3), (0, 0))), structure=np.ones(3, dtype=bool)[:, None])[3:-3]
+    assert np.array_equal(b, orc.fill_holes_mesh(closed, mask, nb0, 2))
+    f, thr, big, n0, n1 = tp.filter_small_objects(b, 0.5, mask=mask, neighbours=nb1)
+    e = orc.filter_small_objects_mesh(b, mask, nb0, 0.5)
+    assert np.array_equal(f, e[0]) and thr == e[1] and (n0, n1) == (e[3], e[4])
