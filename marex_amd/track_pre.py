@@ -147,3 +147,34 @@ def filter_small_objects(data_bin, area_filter_quartile: float = 0.5, area_filte
     res = r["filtered"].cpu().numpy().astype(bool).reshape(T, ny, nx)
     out = data_bin.copy(data=res) if hasattr(data_bin, "copy") and hasattr(data_bin, "dims") else res
     return out, r["area_threshold"], r["object_areas"].cpu().numpy(), r["n_before"], r["n_after"]
+
+
+def run_preprocess(extreme_events, mask, R_fill: int, T_fill: int = 2, area_filter_quartile: float = 0.5,
+                   area_filter_absolute=None, regional_mode: bool = False, device: int = 0):
+    """The whole pre-processing stage of ``marEx.tracker.run_preprocess`` (track.py:1283-1360) for gridded data, on the
+    device without intermediate host copies: ``fill_holes`` -> ``fill_time_gaps`` -> ``filter_small_objects``.
+
+    Returns ``(data_bin_filtered, object_stats)`` with ``object_stats = (total_area_IDed, N_objects_prefiltered,
+    N_objects_filtered, area_threshold, accepted_area_fraction, preprocessed_area_fraction)`` as in the reference
+    (areas in cells; ``accepted_area`` sums the objects STRICTLY above the threshold, as track.py:1337 does)."""
+    import torch
+
+    from .detect import get_engine
+
+    d, m = _check(extreme_events, mask, R_fill, T_fill)
+    eng = get_engine(device)
+    T, ny, nx = d.shape
+    x = torch.from_numpy(_as_u8(d).reshape(T, ny * nx)).to(eng.device)
+    mk = torch.from_numpy(_as_u8(m).reshape(-1)).to(eng.device)
+    raw_area = float(x.sum().item())
+    a = eng.fill_holes(x, mk, ny, nx, int(R_fill), regional_mode)
+    g = eng.fill_time_gaps(a, mk, ny, nx, int(R_fill), int(T_fill), regional_mode)
+    r = eng.filter_small_objects(g, ny, nx, area_filter_quartile, area_filter_absolute, regional_mode)
+    eng.sync()
+    areas = r["object_areas"].to(torch.float64)
+    total = float(areas.sum().item())
+    accepted = float(areas[areas > r["area_threshold"]].sum().item())
+    processed = float(r["filtered"].sum().item())
+    res = r["filtered"].cpu().numpy().astype(bool).reshape(T, ny, nx)
+    stats = (total, r["n_before"], r["n_after"], r["area_threshold"], accepted / total, raw_area / processed if processed else float("nan"))
+    return _wrap(extreme_events, res), stats

@@ -162,3 +162,18 @@ def test_mesh_api(hot):
     f, thr, big, n0, n1 = tp.filter_small_objects(b, 0.5, mask=mask, neighbours=nb1)
     e = orc.filter_small_objects_mesh(b, mask, nb0, 0.5)
     assert np.array_equal(f, e[0]) and thr == e[1] and (n0, n1) == (e[3], e[4])
+
+
+def test_run_preprocess_chain(hot):
+    """fill_holes -> fill_time_gaps -> filter_small_objects in one call (track.py:1283-1360) vs the oracle chain."""
+    rng = np.random.default_rng(9)
+    T, ny, nx = 16, 60, 120
+    x, mask = _blobs(rng, T, ny, nx, 0.12)
+    got, stats = tp.run_preprocess(x, mask, R_fill=3, T_fill=2, area_filter_quartile=0.5)
+    a = orc.fill_holes(x, mask, 3)
+    g = orc.fill_time_gaps(a, mask, 3, 2)
+    e, thr, areas, n0, n1 = orc.filter_small_objects(g, 0.5)
+    assert np.array_equal(got, e)
+    assert stats[1] == n0 and stats[2] == n1 and stats[3] == thr and stats[0] == areas.sum()
+    assert abs(stats[4] - areas[areas > thr].sum() / areas.sum()) < 1e-12
+    assert abs(stats[5] - x.sum() / e.sum()) < 1e-12
