@@ -177,3 +177,19 @@ def test_run_preprocess_chain(hot):
     assert stats[1] == n0 and stats[2] == n1 and stats[3] == thr and stats[0] == areas.sum()
     assert abs(stats[4] - areas[areas > thr].sum() / areas.sum()) < 1e-12
     assert abs(stats[5] - x.sum() / e.sum()) < 1e-12
+
+
+@pytest.mark.parametrize("regional", [False, True])
+def test_connected_components_dense_fields(hot, regional):
+    """Dense noise, full rows and an all-True image: long overlaps between rows, including ones that go all the way
+    round a periodic row (the union-per-overlap shortcut must still link them)."""
+    rng = np.random.default_rng(31)
+    for (T, ny, nx, dens) in ((3, 40, 130, 0.7), (3, 33, 64, 0.9), (2, 20, 70, 1.0), (4, 25, 129, 0.5)):
+        x = rng.random((T, ny, nx)) < dens
+        x[0, 3:6, :] = True          # full rows, stacked
+        x[-1, :, 0] = True
+        x[-1, :, -1] = True
+        exp = orc.label_objects_2d(x, wrap_x=not regional)
+        r = hot.label_objects_2d(torch.from_numpy(x.reshape(T, -1).astype(np.uint8)).to(hot.device), ny, nx, wrap_x=not regional)
+        hot.sync()
+        assert _same_partition(r["labels"].cpu().numpy().reshape(T, ny, nx), exp), (regional, T, ny, nx, dens)
