@@ -234,6 +234,12 @@ int marex_fill_holes_mesh_u8(marex_ctx* ctx, const uint8_t* data, const uint8_t*
 int marex_label_mesh_i32(marex_ctx* ctx, const uint8_t* data, const uint8_t* mask, const int32_t* nbr, int64_t T, int64_t C,
                          int32_t* labels, int32_t* areas);
 
+/* Host-side (the only entry point taking HOST pointers, hence "_h"): decode one Blosc-1 frame -- LZ4 codec or memcpy,
+ * byte shuffle or none -- the chunk format of the reference's Zarr v2 stores ({"id": "blosc", "cname": "lz4",
+ * "shuffle": 1}; examples/batch jobs/run_detect.py:55-83, the fixtures under tests/data).  0 = OK and *out_len = decoded bytes;
+ * -5 malformed frame, -6 unsupported codec / filter. */
+int marex_blosc_decompress_h(const void* src, int64_t srclen, void* dst, int64_t dstcap, int64_t* out_len);
+
 /* out[c, r] = in[r, c]  (thresholds [366, C] -> the reference's (cells, dayofyear) order) */
 int marex_transpose_f32(marex_ctx* ctx, const float* in, int64_t rows, int64_t cols, float* out);
 

@@ -132,3 +132,25 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def make_fixture_stats():
+    """Decode the reference's ORIGINAL zarr fixtures (tests/data/*.zarr under /root/reference) with this repository's
+    decoder and record shapes / checksums: tests/test_zarr_fixtures.py checks that the byte-for-byte copies committed
+    under tests/golden/ref_fixtures decode to the same arrays (run by hand in the build container)."""
+    import hashlib
+    import json
+
+    from marex_amd import zarr_io as z
+
+    R = "/root/reference/tests/data"
+    arrays = {
+        "sst_to_first5490": z.read_array(R + "/sst_gridded.zarr/to")[:5490],
+        "sst_time_first5490": z.read_array(R + "/sst_gridded.zarr/time")[:5490],
+        "extreme_events": z.read_array(R + "/extremes_gridded.zarr/extreme_events"),
+        "mask": z.read_array(R + "/extremes_gridded.zarr/mask"),
+    }
+    out = {k: {"shape": list(v.shape), "dtype": str(v.dtype),
+               "sha256": hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest(),
+               "sum": float(np.asarray(v, dtype=np.float64).sum())} for k, v in arrays.items()}
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_fixtures", "decoded_stats.json"), "w"), indent=1)

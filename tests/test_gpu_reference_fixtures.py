@@ -1,0 +1,95 @@
+"""GPU: the reference's own tests, re-expressed on the reference's own fixture data (tests/golden/ref_fixtures, read with
+marex_amd.zarr_io) -- plus bit parity with the oracle on that real SST field.
+
+* tests/test_gridded_preprocessing.py:35-88  (shifting_baseline + hobday_extreme on sst_gridded.zarr)
+* tests/test_gridded_preprocessing.py:735-771 (all anomaly x extreme method pairs: frequency in 2.5 % .. 7.5 %)
+* the tracker's pre-processing on extremes_gridded.zarr with the parameters of tests/test_gridded_tracking.py:28-35, 85-91
+The SST fixture is cut to its first 5490 days (15 years), so the pairs with shifting_baseline use window_year_baseline = 5
+(the reference's default of 15 needs more than 15 years).
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+import marex_amd
+import marex_amd.track_pre as tp
+from marex_amd import binning, calendar, zarr_io
+from marex_amd.xr_compat import DataArray
+from oracle import marex_oracle as orc
+
+pytestmark = pytest.mark.gpu
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fixtures")
+
+
+@pytest.fixture(scope="module")
+def sst():
+    p = os.path.join(FIX, "sst_gridded.zarr")
+    x = zarr_io.read_array(os.path.join(p, "to"))[:5490].copy()
+    tm = zarr_io.decode_cf_time(zarr_io.read_array(os.path.join(p, "time"))[:5490], zarr_io.array_attrs(os.path.join(p, "time")))
+    x[:, 1, 1] = np.nan  # the reference's setup_class masks the 2nd lat / 2nd lon point (test_gridded_preprocessing.py:22-25)
+    lat, lon = np.linspace(35.0, 44.5, 20), np.linspace(-40.0, -20.5, 40)  # the zstd-compressed coordinate arrays are not decoded
+    return DataArray(x, dims=("time", "lat", "lon"), coords={"time": tm, "lat": lat, "lon": lon}, name="to"), tm
+
+
+def test_shifting_baseline_hobday_extreme_like_the_reference(hot, sst):
+    da, tm = sst
+    W = 5
+    ds = marex_amd.preprocess_data(da, method_anomaly="shifting_baseline", method_extreme="hobday_extreme", threshold_percentile=95,
+                                   window_year_baseline=W, smooth_days_baseline=11, window_days_hobday=3,
+                                   dimensions={"time": "time", "x": "lon", "y": "lat"}, dask_chunks={"time": 25})
+    for v in ("extreme_events", "dat_anomaly", "thresholds", "mask"):
+        assert v in ds.data_vars
+    assert ds.attrs["method_anomaly"] == "shifting_baseline" and ds.attrs["method_extreme"] == "hobday_extreme"
+    assert ds.attrs["threshold_percentile"] == 95
+    assert ds.extreme_events.dtype == bool and ds.dat_anomaly.dtype == np.float32
+    assert ds.extreme_events.dims == ("time", "lat", "lon") and "dayofyear" in ds.thresholds.dims
+    reduction = da.shape[0] - ds.extreme_events.shape[0]
+    assert abs(reduction - W * 365) <= 10                       # test_gridded_preprocessing.py:71-83
+    freq = float(ds.extreme_events.values.mean())
+    assert 0.04 <= freq <= 0.06, freq                           # conftest.py:215-231 (5 % +- max(0.5 %, 20 % rel))
+    # bit parity with the oracle on this real field (gridded default 5x5 pooling, detect.py:1451-1452)
+    cal = calendar.build_calendar(tm, window_year_baseline=W)
+    bt = binning.hobday_bins()
+    exp = orc.preprocess_arrays(da.values.reshape(da.shape[0], -1), cal, ny=20, nx=40, window_year_baseline=W,
+                                smooth_days_baseline=11, window_days_hobday=3, window_spatial_hobday=5,
+                                threshold_percentile=95.0, edges=bt.edges, centres=bt.centres)
+    assert np.array_equal(ds.dat_anomaly.values.reshape(-1, 800), exp["dat_anomaly"], equal_nan=True)
+    assert np.array_equal(ds.thresholds.values.reshape(800, 366), exp["thresholds"], equal_nan=True)
+    assert np.array_equal(ds.extreme_events.values.reshape(-1, 800), exp["extreme_events"])
+    assert not ds.mask.values[1, 1] and ds.mask.values.sum() == 799
+
+
+@pytest.mark.parametrize("ma,me", [
+    ("fixed_baseline", "global_extreme"), ("fixed_baseline", "hobday_extreme"),
+    ("detrend_fixed_baseline", "global_extreme"), ("detrend_fixed_baseline", "hobday_extreme"),
+    ("shifting_baseline", "global_extreme"), ("shifting_baseline", "hobday_extreme"),
+    ("detrend_harmonic", "global_extreme"), ("detrend_harmonic", "hobday_extreme"),
+])
+def test_all_method_pairs_like_the_reference(hot, sst, ma, me):
+    da, _ = sst
+    kw = dict(window_year_baseline=5) if ma == "shifting_baseline" else {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ds = marex_amd.preprocess_data(da, method_anomaly=ma, method_extreme=me, threshold_percentile=95,
+                                       window_days_hobday=11, dimensions={"time": "time", "x": "lon", "y": "lat"},
+                                       dask_chunks={"time": 25}, **kw)
+    assert "extreme_events" in ds.data_vars and ds.attrs["method_anomaly"] == ma and ds.attrs["method_extreme"] == me
+    freq = float(ds.extreme_events.values.mean())
+    assert 0.025 < freq < 0.075, (ma, me, freq)                 # test_gridded_preprocessing.py:767-771
+
+
+@pytest.mark.parametrize("R_fill,T_fill", [(4, 0), (4, 2), (8, 2)])
+def test_tracker_preprocessing_on_the_reference_extremes(hot, R_fill, T_fill):
+    p = os.path.join(FIX, "extremes_gridded.zarr")
+    ev = zarr_io.read_array(os.path.join(p, "extreme_events")).astype(bool)
+    mask = zarr_io.read_array(os.path.join(p, "mask")).astype(bool)
+    assert ev.shape == (32, 180, 360) and 0.05 < ev.mean() < 0.10
+    got, stats = tp.run_preprocess(ev, mask, R_fill=R_fill, T_fill=T_fill, area_filter_quartile=0.5)
+    a = orc.fill_holes(ev, mask, R_fill)
+    g = orc.fill_time_gaps(a, mask, R_fill, T_fill)
+    e, thr, areas, n0, n1 = orc.filter_small_objects(g, 0.5)
+    assert np.array_equal(got, e)
+    assert (stats[1], stats[2], stats[3]) == (n0, n1, thr) and n0 > n1 > 0
+    assert not got[:, ~mask].any()

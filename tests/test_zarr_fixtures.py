@@ -1,0 +1,53 @@
+"""CPU: the Zarr v2 / Blosc-LZ4 reader (host side of the C ABI) on the data files of the reference's own tests."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from marex_amd import _lib, zarr_io
+
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fixtures")
+STATS = json.load(open(os.path.join(FIX, "decoded_stats.json")))
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_fixture_copies_decode_like_the_originals():
+    sst = zarr_io.read_array(os.path.join(FIX, "sst_gridded.zarr", "to"))[:5490]
+    tm = zarr_io.read_array(os.path.join(FIX, "sst_gridded.zarr", "time"))[:5490]
+    ev = zarr_io.read_array(os.path.join(FIX, "extremes_gridded.zarr", "extreme_events"))
+    mk = zarr_io.read_array(os.path.join(FIX, "extremes_gridded.zarr", "mask"))
+    for key, arr in (("sst_to_first5490", sst), ("sst_time_first5490", tm), ("extreme_events", ev), ("mask", mk)):
+        assert list(arr.shape) == STATS[key]["shape"] and str(arr.dtype) == STATS[key]["dtype"]
+        assert _sha(arr) == STATS[key]["sha256"], key
+    # what the data is: 15 years of daily SST in kelvin on a 20 x 40 patch, CF time axis
+    t = zarr_io.decode_cf_time(tm, zarr_io.array_attrs(os.path.join(FIX, "sst_gridded.zarr", "time")))
+    assert str(t[0]) == "1982-01-01T12:00:00" and np.all(np.diff(t).astype("timedelta64[s]").astype(int) == 86400)
+    assert sst.dtype == np.float32 and 280 < sst.min() < sst.max() < 310 and np.isfinite(sst).all()
+    assert set(np.unique(ev)) <= {0, 1} and set(np.unique(mk)) <= {0, 1}
+
+
+def test_decoder_rejects_damaged_and_foreign_frames():
+    lib = _lib.load()
+    f = os.path.join(FIX, "sst_gridded.zarr", "to", "0.0.0")
+    raw = open(f, "rb").read()
+    n = C.c_int64(0)
+    out = C.create_string_buffer(30 * 20 * 40 * 4)
+    assert lib.marex_blosc_decompress_h(raw, len(raw), out, len(out), C.byref(n)) == 0 and n.value == len(out)
+    good = bytes(out.raw)
+    assert lib.marex_blosc_decompress_h(raw, len(raw) // 2, out, len(out), C.byref(n)) != 0        # truncated
+    assert lib.marex_blosc_decompress_h(raw, len(raw), out, 100, C.byref(n)) != 0                  # destination too small
+    zstd = bytearray(raw)
+    zstd[2] = (zstd[2] & 0x1F) | (4 << 5)                                                           # codec id: zstd
+    assert lib.marex_blosc_decompress_h(bytes(zstd), len(zstd), out, len(out), C.byref(n)) == -6
+    bad = bytearray(raw)
+    bad[200:260] = b"\\xff" * 60                                                                     # garbage inside a stream
+    rc = lib.marex_blosc_decompress_h(bytes(bad), len(bad), out, len(out), C.byref(n))
+    assert rc != 0 or bytes(out.raw) != good
+    with pytest.raises(Exception):
+        zarr_io.read_array(os.path.join(FIX, "sst_gridded.zarr", "nothing_here"))
