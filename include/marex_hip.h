@@ -240,6 +240,19 @@ int marex_label_mesh_i32(marex_ctx* ctx, const uint8_t* data, const uint8_t* mas
  * -5 malformed frame, -6 unsupported codec / filter. */
 int marex_blosc_decompress_h(const void* src, int64_t srclen, void* dst, int64_t dstcap, int64_t* out_len);
 
+/* Device-side chunk decoding (compressed bytes cross PCIe, the field is born in HBM): n_streams LZ4 block streams --
+ * stream s = comp[src_off[s] .. +csize[s]) -> planes[dst_off[s] .. +rawsz[s]) (csize == rawsz: stored, copied) -- one
+ * wave each; *status (device int, zeroed by the caller) counts malformed streams.  Then marex_unshuffle_place turns the
+ * byte planes of every Blosc block (planes + blk_off[b], blk_ne[b] elements of `typesize` bytes, byte-shuffled or not)
+ * into elements blk_elem0[b] .. +blk_valid[b] of the destination array `out`.  The host parses the frame headers
+ * (marex_amd/zarr_io.py). */
+int marex_lz4_decode_streams(marex_ctx* ctx, const uint8_t* comp, const int64_t* src_off, const int32_t* csize,
+                             const int64_t* dst_off, const int32_t* rawsz, int n_streams, int max_raw, uint8_t* planes,
+                             int32_t* status);
+int marex_unshuffle_place(marex_ctx* ctx, const uint8_t* planes, const int64_t* blk_off, const int64_t* blk_elem0,
+                          const int32_t* blk_ne, const int32_t* blk_valid, int n_blocks, int max_ne, int typesize, int shuffled,
+                          uint8_t* out);
+
 /* out[c, r] = in[r, c]  (thresholds [366, C] -> the reference's (cells, dayofyear) order) */
 int marex_transpose_f32(marex_ctx* ctx, const float* in, int64_t rows, int64_t cols, float* out);
 

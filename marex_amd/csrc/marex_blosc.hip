@@ -112,3 +112,150 @@ extern "C" int marex_blosc_decompress_h(const void* src_v, int64_t srclen, void*
     }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Device side: decode many LZ4 streams at once (one wave per stream) and undo the byte shuffle while placing the
+// elements in the destination array -- compressed chunks go over PCIe, the float field is born in HBM.
+//
+// A wave walks its stream's sequences in lock step (token / lengths / offset are wave-uniform); literal and match
+// copies are spread over the 64 lanes.  Matches are served from an LDS ring that mirrors the last RING bytes of the
+// output (RING >= 64 KiB whenever the stream is longer than that: LZ4 offsets reach 65 535 bytes back), so nothing is
+// ever re-read from global memory; every step reads all its sources before it writes, and long overlapping matches
+// (runs) are cut into pieces so that their source bytes are still in the ring.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_lz4_streams(const unsigned char* __restrict__ comp, const long* __restrict__ src_off, const int* __restrict__ csize,
+              const long* __restrict__ dst_off, const int* __restrict__ rawsz, int ring_mask,
+              unsigned char* __restrict__ out, int* __restrict__ status) {
+    extern __shared__ unsigned char ring[];
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const unsigned char* src = comp + src_off[s];
+    unsigned char* dst = out + dst_off[s];
+    const int cs = csize[s], raw = rawsz[s];
+    if (cs == raw) {  // stored split
+        for (int i = lane; i < raw; i += 64) dst[i] = src[i];
+        return;
+    }
+    int ip = 0, op = 0;
+    bool bad = false;
+    while (ip < cs) {
+        const unsigned token = src[ip++];
+        int lit = (int)(token >> 4);
+        if (lit == 15) {
+            unsigned b = 255;
+            while (b == 255 && ip < cs) {
+                b = src[ip++];
+                lit += (int)b;
+            }
+        }
+        if (lit > cs - ip || lit > raw - op) {
+            bad = true;
+            break;
+        }
+        for (int i = lane; i < lit; i += 64) {
+            const unsigned char c = src[ip + i];
+            ring[(op + i) & ring_mask] = c;
+            dst[op + i] = c;
+        }
+        ip += lit;
+        op += lit;
+        if (ip >= cs) break;  // last sequence: literals only
+        if (cs - ip < 2) {
+            bad = true;
+            break;
+        }
+        const int offset = (int)src[ip] | ((int)src[ip + 1] << 8);
+        ip += 2;
+        int mlen = (int)(token & 15u) + 4;
+        if ((token & 15u) == 15u) {
+            unsigned b = 255;
+            while (b == 255 && ip < cs) {
+                b = src[ip++];
+                mlen += (int)b;
+            }
+        }
+        if (offset == 0 || offset > op || mlen > raw - op) {
+            bad = true;
+            break;
+        }
+        __builtin_amdgcn_s_waitcnt(0);  // the literals are in the ring before anybody reads them back
+        if (offset >= 64) {
+            for (int base = 0; base < mlen; base += 64) {
+                const int i = base + lane;
+                unsigned char v = 0;
+                if (i < mlen) v = ring[(op - offset + i) & ring_mask];
+                __builtin_amdgcn_s_waitcnt(0);
+                if (i < mlen) {
+                    ring[(op + i) & ring_mask] = v;
+                    dst[op + i] = v;
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+        } else {  // the last `offset` bytes repeat: pieces short enough that their source stays in the ring
+            int done = 0;
+            while (done < mlen) {
+                const int piece = mlen - done < 8192 ? mlen - done : 8192;
+                const int o = op + done;
+                for (int i = lane; i < piece; i += 64) {
+                    const unsigned char v = ring[(o - offset + (i % offset)) & ring_mask];
+                    ring[(o + i) & ring_mask] = v;
+                    dst[o + i] = v;
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                done += piece;
+            }
+        }
+        op += mlen;
+    }
+    if (lane == 0 && (bad || op != raw)) atomicAdd(status, 1);
+}
+
+// byte planes of a shuffled block -> elements at their place in the destination (typesize bytes each)
+__global__ void __launch_bounds__(256)
+k_unshuffle_place(const unsigned char* __restrict__ planes, const long* __restrict__ blk_off, const long* __restrict__ blk_elem0,
+                  const int* __restrict__ blk_ne, const int* __restrict__ blk_valid, int typesize, int shuffled,
+                  unsigned char* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int e = (int)blockIdx.x * 256 + threadIdx.x;
+    if (e >= blk_valid[b]) return;
+    const int ne = blk_ne[b];
+    const unsigned char* p = planes + blk_off[b];
+    unsigned char* o = out + (size_t)(blk_elem0[b] + e) * typesize;
+    if (shuffled) {
+        for (int k = 0; k < typesize; ++k) o[k] = p[(size_t)k * ne + e];
+    } else {
+        for (int k = 0; k < typesize; ++k) o[k] = p[(size_t)e * typesize + k];
+    }
+}
+
+extern "C" int marex_lz4_decode_streams(marex_ctx* ctx, const uint8_t* comp, const int64_t* src_off, const int32_t* csize,
+                                        const int64_t* dst_off, const int32_t* rawsz, int n_streams, int max_raw,
+                                        uint8_t* planes, int32_t* status) {
+    if (!ctx) return -1;
+    if (!comp || !src_off || !csize || !dst_off || !rawsz || !planes || !status || n_streams <= 0 || max_raw <= 0)
+        return fail(ctx, -1, "marex_lz4_decode_streams: null pointer or empty table");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int ring = 1024;
+    while (ring < max_raw && ring < 65536) ring <<= 1;
+    if (ring > 48 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_lz4_streams, hipFuncAttributeMaxDynamicSharedMemorySize, ring));
+    hipLaunchKernelGGL(k_lz4_streams, dim3((unsigned)n_streams), dim3(64), (size_t)ring, ctx->stream, comp,
+                       reinterpret_cast<const long*>(src_off), csize, reinterpret_cast<const long*>(dst_off), rawsz, ring - 1, planes,
+                       status);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int marex_unshuffle_place(marex_ctx* ctx, const uint8_t* planes, const int64_t* blk_off, const int64_t* blk_elem0,
+                                     const int32_t* blk_ne, const int32_t* blk_valid, int n_blocks, int max_ne, int typesize,
+                                     int shuffled, uint8_t* out) {
+    if (!ctx) return -1;
+    if (!planes || !blk_off || !blk_elem0 || !blk_ne || !blk_valid || !out || n_blocks <= 0 || max_ne <= 0 || typesize < 1)
+        return fail(ctx, -1, "marex_unshuffle_place: null pointer or empty table");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_unshuffle_place, dim3((unsigned)((max_ne + 255) / 256), (unsigned)n_blocks), dim3(256), 0, ctx->stream, planes,
+                       reinterpret_cast<const long*>(blk_off), reinterpret_cast<const long*>(blk_elem0), blk_ne, blk_valid, typesize,
+                       shuffled, out);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}

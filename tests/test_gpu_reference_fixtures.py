@@ -93,3 +93,15 @@ def test_tracker_preprocessing_on_the_reference_extremes(hot, R_fill, T_fill):
     assert np.array_equal(got, e)
     assert (stats[1], stats[2], stats[3]) == (n0, n1, thr) and n0 > n1 > 0
     assert not got[:, ~mask].any()
+
+
+def test_device_chunk_decoder_equals_the_host_decoder(hot):
+    """Compressed chunks -> HBM (LZ4 streams decoded one wave each, byte shuffle undone on placement) == host decode."""
+    for sub, lead in (("sst_gridded.zarr/to", 5490), ("sst_gridded.zarr/to", 47), ("extremes_gridded.zarr/extreme_events", None),
+                      ("extremes_gridded.zarr/extreme_events", 3), ("extremes_gridded.zarr/mask", None)):
+        p = os.path.join(FIX, *sub.split("/"))
+        host = zarr_io.read_array(p)
+        host = host if lead is None else host[:lead]
+        dev = zarr_io.read_array_to_device(p, hot, lead)
+        assert tuple(dev.shape) == host.shape
+        assert np.array_equal(dev.cpu().numpy(), host), sub
