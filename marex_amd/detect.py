@@ -144,10 +144,22 @@ class _Field:
                 f"Unsupported extra dimensions {extra}", details="expected (time, y, x) or (time, cells) data"
             )
         self.da = da
-        arr = to_numpy(da.transpose(self.tdim, *self.sdims))
-        self.sshape = tuple(arr.shape[1:])
+        dev = getattr(da, "device_tensor", None)
+        if dev is not None:  # field already in HBM (marex_amd.zarr_io.open_dataarray_device): no host copy, no upload
+            if tuple(da.dims) != (self.tdim, *self.sdims):
+                raise create_data_validation_error("device-resident input must be laid out (time, y, x) / (time, cells)",
+                                                   details=f"dims {tuple(da.dims)}")
+            self.sshape = tuple(dev.shape[1:])
+            self.x = None
+            self._x_dev = dev.reshape(dev.shape[0], -1)
+            self.shape = tuple(self._x_dev.shape)
+        else:
+            arr = to_numpy(da.transpose(self.tdim, *self.sdims))
+            self.sshape = tuple(arr.shape[1:])
+            self.x = np.ascontiguousarray(arr.reshape(arr.shape[0], -1), dtype=np.float32)  # cast as detect.py:600
+            self._x_dev = None
+            self.shape = tuple(self.x.shape)
         self.ny, self.nx = (self.sshape if self.gridded else (0, self.sshape[0]))
-        self.x = np.ascontiguousarray(arr.reshape(arr.shape[0], -1), dtype=np.float32)  # cast as detect.py:600
         self.time = coord_values(da, coordinates["time"])
         self.scoords = {}
         for d in self.sdims:
@@ -157,6 +169,14 @@ class _Field:
             name = coordinates.get(key)
             if name is not None and name in da.coords and name not in self.scoords:
                 self.scoords[name] = da.coords[name]
+
+    def device_x(self, eng):
+        """The field as a float32 ``[T, C]`` tensor on the engine's device (cast as detect.py:600)."""
+        import torch
+
+        if self._x_dev is not None:
+            return self._x_dev.to(device=eng.device, dtype=torch.float32).contiguous()
+        return torch.from_numpy(self.x).to(eng.device)
 
     def labelled(self, data: np.ndarray, lead: Optional[Tuple[str, np.ndarray]], trail: Optional[Tuple[str, np.ndarray]] = None):
         """Wrap ``data`` with dims ``(lead?, *spatial, trail?)``; ``data``'s cell axis is still flat."""
@@ -173,7 +193,7 @@ class _Field:
 
 def _raise_if_invalid(field: _Field, summary: Dict[str, int]) -> None:
     """Error texts of ``_validate_data_values`` (detect.py:224-279) from the device-side counts."""
-    T, C = field.x.shape
+    T, C = field.shape
     if summary["n_ocean"] == 0:
         raise create_data_validation_error(
             "Dataset contains no valid (finite) data",
@@ -346,7 +366,7 @@ def _anomaly_core(eng, field: _Field, method_anomaly, window_year_baseline, smoo
     """Runs the anomaly stage on the device.  Returns dict with device tensors + the calendar plan."""
     import torch
 
-    x = torch.from_numpy(field.x).to(eng.device)
+    x = field.device_x(eng)
     if method_anomaly == "shifting_baseline":
         cal = calendar.build_calendar(field.time, window_year_baseline=int(window_year_baseline))
         total_years = cal.n_cal_years
@@ -649,7 +669,7 @@ def compute_normalised_anomaly(
     cal = a["cal"]
     anom = a["anom"].cpu().numpy()
     if method_anomaly == "shifting_baseline":
-        full = np.full(field.x.shape, np.nan, dtype=np.float32)
+        full = np.full(field.shape, np.nan, dtype=np.float32)
         full[cal.kept] = anom
         anom = full
     ds = Dataset()
@@ -694,7 +714,7 @@ def identify_extremes(
     bt = binning.hobday_bins(precision, max_anomaly) if method_percentile == "approximate" else None
     cal = calendar.build_calendar(field.time)
     dcal = eng.upload_calendar(cal)
-    anom = torch.from_numpy(field.x).to(eng.device)
+    anom = field.device_x(eng)
     a = {"anom": anom, "cal": cal, "dcal": dcal, "bins": None}
     if method_extreme == "hobday_extreme" and method_percentile == "approximate":
         a["bins"] = eng.digitize(anom, dcal, bt)
@@ -721,10 +741,10 @@ def _climatology(da, window_year_baseline, smooth_days, dimensions, coordinates,
 
     cal_trim = calendar.build_calendar(field.time, window_year_baseline=int(window_year_baseline))
     dcal = eng.upload_calendar(cal_trim)
-    x = torch.from_numpy(field.x).to(eng.device)
+    x = field.device_x(eng)
     r = eng.shifting_baseline(x, dcal, int(window_year_baseline), int(smooth_days), None, write_clim=True)
     eng.sync()
-    full = np.full(field.x.shape, np.nan, dtype=np.float32)
+    full = np.full(field.shape, np.nan, dtype=np.float32)
     full[cal_trim.kept] = r["out"].cpu().numpy()
     return field.labelled(full, (field.tdim, field.time))
 

@@ -156,3 +156,45 @@ def read_array_to_device(path: str, eng, lead: int | None = None):
     tdt = {"float32": torch.float32, "float64": torch.float64, "int32": torch.int32, "int64": torch.int64, "int8": torch.int8,
            "uint8": torch.uint8, "int16": torch.int16}[dtype.name]
     return out.view(tdt).reshape((T,) + shape[1:])
+
+
+class DeviceDataArray:
+    """A labelled array whose data lives in HBM: ``dims`` / ``coords`` / ``attrs`` like a DataArray, the data itself a
+    torch tensor in ``device_tensor``.  ``marex_amd.preprocess_data`` & co. take it without a host copy or an upload."""
+
+    def __init__(self, device_tensor, dims, coords, name=None, attrs=None):
+        self.device_tensor = device_tensor
+        self.dims = tuple(dims)
+        self.coords = {k: (v if hasattr(v, "values") else _Coord(np.asarray(v))) for k, v in coords.items()}
+        self.name = name
+        self.attrs = dict(attrs or {})
+        self.shape = tuple(device_tensor.shape)
+        self.dtype = np.dtype(str(device_tensor.dtype).replace("torch.", ""))
+
+    @property
+    def sizes(self):
+        return dict(zip(self.dims, self.shape))
+
+    @property
+    def values(self):
+        return self.device_tensor.cpu().numpy()
+
+
+class _Coord:
+    def __init__(self, values):
+        self.values = values
+
+    def __len__(self):
+        return len(self.values)
+
+
+def open_dataarray_device(store: str, variable: str, eng, dims, time_var: str = "time", lead: int | None = None, coords=None):
+    """``xr.open_zarr(store)[variable]`` for the device: the variable's chunks are decoded in HBM
+    (``read_array_to_device``), the CF time axis on the host.  ``dims`` names the dimensions, ``coords`` may add spatial
+    coordinate arrays (the reference's coordinate arrays are zstd-compressed, which the decoder does not cover)."""
+    x = read_array_to_device(os.path.join(store, variable), eng, lead)
+    tpath = os.path.join(store, time_var)
+    tm = decode_cf_time(read_array(tpath)[: x.shape[0]], array_attrs(tpath))
+    c = {dims[0]: tm}
+    c.update(coords or {})
+    return DeviceDataArray(x, dims, c, name=variable, attrs=array_attrs(os.path.join(store, variable)))

@@ -105,3 +105,20 @@ def test_device_chunk_decoder_equals_the_host_decoder(hot):
         dev = zarr_io.read_array_to_device(p, hot, lead)
         assert tuple(dev.shape) == host.shape
         assert np.array_equal(dev.cpu().numpy(), host), sub
+
+
+def test_preprocess_straight_from_the_compressed_store(hot, sst):
+    """Chunks decoded in HBM feed preprocess_data without a host copy of the field: same Dataset as from the host array."""
+    da_host, tm = sst
+    p = os.path.join(FIX, "sst_gridded.zarr")
+    lat, lon = da_host.coords["lat"].values, da_host.coords["lon"].values
+    da_dev = zarr_io.open_dataarray_device(p, "to", hot, dims=("time", "lat", "lon"), lead=5490, coords={"lat": lat, "lon": lon})
+    assert da_dev.device_tensor.is_cuda and da_dev.shape == (5490, 20, 40)
+    da_dev.device_tensor[:, 1, 1] = float("nan")  # the same masked point as the host fixture
+    kw = dict(method_anomaly="shifting_baseline", method_extreme="hobday_extreme", threshold_percentile=95,
+              window_year_baseline=5, smooth_days_baseline=11, window_days_hobday=3)
+    a = marex_amd.preprocess_data(da_host, **kw)
+    b = marex_amd.preprocess_data(da_dev, **kw)
+    for v in ("dat_anomaly", "extreme_events", "thresholds", "mask"):
+        assert np.array_equal(a[v].values, b[v].values, equal_nan=True), v
+    assert np.array_equal(a.dat_anomaly.coords["time"].values, b.dat_anomaly.coords["time"].values)
