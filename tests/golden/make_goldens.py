@@ -149,6 +149,11 @@ def make_fixture_stats():
         "sst_time_first5490": z.read_array(R + "/sst_gridded.zarr/time")[:5490],
         "extreme_events": z.read_array(R + "/extremes_gridded.zarr/extreme_events"),
         "mask": z.read_array(R + "/extremes_gridded.zarr/mask"),
+        "sst_unstructured_to_first5479": z.read_array(R + "/sst_unstructured.zarr/to")[:5479],
+        "sst_unstructured_time_first5479": z.read_array(R + "/sst_unstructured.zarr/time")[:5479],
+        "unstructured_extreme_events": z.read_array(R + "/extremes_unstructured.zarr/extreme_events"),
+        "unstructured_mask": z.read_array(R + "/extremes_unstructured.zarr/mask"),
+        "unstructured_neighbours": z.read_array(R + "/extremes_unstructured.zarr/neighbours"),
     }
     out = {k: {"shape": list(v.shape), "dtype": str(v.dtype),
                "sha256": hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest(),

@@ -25,6 +25,13 @@ def test_fixture_copies_decode_like_the_originals():
     for key, arr in (("sst_to_first5490", sst), ("sst_time_first5490", tm), ("extreme_events", ev), ("mask", mk)):
         assert list(arr.shape) == STATS[key]["shape"] and str(arr.dtype) == STATS[key]["dtype"]
         assert _sha(arr) == STATS[key]["sha256"], key
+    un = os.path.join(FIX, "sst_unstructured.zarr")
+    for key, arr in (("sst_unstructured_to_first5479", zarr_io.read_array(os.path.join(un, "to"))[:5479]),
+                     ("sst_unstructured_time_first5479", zarr_io.read_array(os.path.join(un, "time"))[:5479]),
+                     ("unstructured_extreme_events", zarr_io.read_array(os.path.join(FIX, "extremes_unstructured.zarr", "extreme_events"))),
+                     ("unstructured_mask", zarr_io.read_array(os.path.join(FIX, "extremes_unstructured.zarr", "mask"))),
+                     ("unstructured_neighbours", zarr_io.read_array(os.path.join(FIX, "extremes_unstructured.zarr", "neighbours")))):
+        assert list(arr.shape) == STATS[key]["shape"] and _sha(arr) == STATS[key]["sha256"], key
     # what the data is: 15 years of daily SST in kelvin on a 20 x 40 patch, CF time axis
     t = zarr_io.decode_cf_time(tm, zarr_io.array_attrs(os.path.join(FIX, "sst_gridded.zarr", "time")))
     assert str(t[0]) == "1982-01-01T12:00:00" and np.all(np.diff(t).astype("timedelta64[s]").astype(int) == 86400)
