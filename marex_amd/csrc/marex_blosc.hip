@@ -120,9 +120,21 @@ extern "C" int marex_blosc_decompress_h(const void* src_v, int64_t srclen, void*
 // A wave walks its stream's sequences in lock step (token / lengths / offset are wave-uniform); literal and match
 // copies are spread over the 64 lanes.  Matches are served from an LDS ring that mirrors the last RING bytes of the
 // output (RING >= 64 KiB whenever the stream is longer than that: LZ4 offsets reach 65 535 bytes back), so nothing is
-// ever re-read from global memory; every step reads all its sources before it writes, and long overlapping matches
+// ever re-read from global memory and the wave never waits for its own global stores; every step reads all its sources
+// before it writes (the LDS queue of a wave is in order), and long overlapping matches
 // (runs) are cut into pieces so that their source bytes are still in the ring.
 // ------------------------------------------------------------------------------------------------
+// stored (incompressible) splits: plain copies, spread over many threads
+__global__ void __launch_bounds__(256)
+k_stored_streams(const unsigned char* __restrict__ comp, const long* __restrict__ src_off, const int* __restrict__ csize,
+                 const long* __restrict__ dst_off, const int* __restrict__ rawsz, unsigned char* __restrict__ out) {
+    const int s = blockIdx.y;
+    const int raw = rawsz[s];
+    if (csize[s] != raw) return;
+    const int i = (int)blockIdx.x * 256 + threadIdx.x;
+    if (i < raw) out[dst_off[s] + i] = comp[src_off[s] + i];
+}
+
 __global__ void __launch_bounds__(64)
 k_lz4_streams(const unsigned char* __restrict__ comp, const long* __restrict__ src_off, const int* __restrict__ csize,
               const long* __restrict__ dst_off, const int* __restrict__ rawsz, int ring_mask,
@@ -132,19 +144,17 @@ k_lz4_streams(const unsigned char* __restrict__ comp, const long* __restrict__ s
     const unsigned char* src = comp + src_off[s];
     unsigned char* dst = out + dst_off[s];
     const int cs = csize[s], raw = rawsz[s];
-    if (cs == raw) {  // stored split
-        for (int i = lane; i < raw; i += 64) dst[i] = src[i];
-        return;
-    }
+    if (cs == raw) return;  // stored split: k_stored_streams
+    auto byte_at = [&](int p) -> unsigned { return src[p]; };  // wave-uniform address: one broadcast load (L1 resident)
     int ip = 0, op = 0;
     bool bad = false;
     while (ip < cs) {
-        const unsigned token = src[ip++];
+        const unsigned token = byte_at(ip++);
         int lit = (int)(token >> 4);
         if (lit == 15) {
             unsigned b = 255;
             while (b == 255 && ip < cs) {
-                b = src[ip++];
+                b = byte_at(ip++);
                 lit += (int)b;
             }
         }
@@ -153,7 +163,7 @@ k_lz4_streams(const unsigned char* __restrict__ comp, const long* __restrict__ s
             break;
         }
         for (int i = lane; i < lit; i += 64) {
-            const unsigned char c = src[ip + i];
+            const unsigned char c = (unsigned char)byte_at(ip + i);
             ring[(op + i) & ring_mask] = c;
             dst[op + i] = c;
         }
@@ -164,13 +174,14 @@ k_lz4_streams(const unsigned char* __restrict__ comp, const long* __restrict__ s
             bad = true;
             break;
         }
-        const int offset = (int)src[ip] | ((int)src[ip + 1] << 8);
+        const unsigned o_lo = byte_at(ip), o_hi = byte_at(ip + 1);
+        const int offset = (int)(o_lo | (o_hi << 8));
         ip += 2;
         int mlen = (int)(token & 15u) + 4;
         if ((token & 15u) == 15u) {
             unsigned b = 255;
             while (b == 255 && ip < cs) {
-                b = src[ip++];
+                b = byte_at(ip++);
                 mlen += (int)b;
             }
         }
@@ -178,18 +189,18 @@ k_lz4_streams(const unsigned char* __restrict__ comp, const long* __restrict__ s
             bad = true;
             break;
         }
-        __builtin_amdgcn_s_waitcnt(0);  // the literals are in the ring before anybody reads them back
+        __builtin_amdgcn_s_waitcnt(0xC07F);  /* lgkmcnt(0): LDS only, never the global stores */  // the literals are in the ring before anybody reads them back
         if (offset >= 64) {
             for (int base = 0; base < mlen; base += 64) {
                 const int i = base + lane;
                 unsigned char v = 0;
                 if (i < mlen) v = ring[(op - offset + i) & ring_mask];
-                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);  /* lgkmcnt(0): LDS only, never the global stores */
                 if (i < mlen) {
                     ring[(op + i) & ring_mask] = v;
                     dst[op + i] = v;
                 }
-                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);  /* lgkmcnt(0): LDS only, never the global stores */
             }
         } else {  // the last `offset` bytes repeat: pieces short enough that their source stays in the ring
             int done = 0;
@@ -201,7 +212,7 @@ k_lz4_streams(const unsigned char* __restrict__ comp, const long* __restrict__ s
                     ring[(o + i) & ring_mask] = v;
                     dst[o + i] = v;
                 }
-                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);  /* lgkmcnt(0): LDS only, never the global stores */
                 done += piece;
             }
         }
@@ -236,9 +247,11 @@ extern "C" int marex_lz4_decode_streams(marex_ctx* ctx, const uint8_t* comp, con
         return fail(ctx, -1, "marex_lz4_decode_streams: null pointer or empty table");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int ring = 1024;
-    while (ring < max_raw && ring < 65536) ring <<= 1;
+    while (ring < max_raw && ring < 65536) ring <<= 1;  // power of two: ring positions are masked
     if (ring > 48 * 1024)
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_lz4_streams, hipFuncAttributeMaxDynamicSharedMemorySize, ring));
+    hipLaunchKernelGGL(k_stored_streams, dim3((unsigned)((max_raw + 255) / 256), (unsigned)n_streams), dim3(256), 0, ctx->stream, comp,
+                       reinterpret_cast<const long*>(src_off), csize, reinterpret_cast<const long*>(dst_off), rawsz, planes);
     hipLaunchKernelGGL(k_lz4_streams, dim3((unsigned)n_streams), dim3(64), (size_t)ring, ctx->stream, comp,
                        reinterpret_cast<const long*>(src_off), csize, reinterpret_cast<const long*>(dst_off), rawsz, ring - 1, planes,
                        status);
