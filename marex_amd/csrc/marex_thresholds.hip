@@ -239,7 +239,7 @@ k_thresholds(const unsigned short* __restrict__ bins, long T_out, long C, int ny
 #endif
 
 template <int P, int TC, int NT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, NT == 256 ? 4 : 1)
 k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, int nx, int row0, int row1, int tiles_x,
            int Dd, int shift, int env_exact, int ablate, const int* __restrict__ doy_start,
            const float* __restrict__ first_anom, const float* __restrict__ centres, int nb, double q, int wd,
@@ -250,13 +250,10 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
     // lane-major level columns: TB_LS dwords (= 68 uint16 levels) per lane.  The stride 34 keeps 8-byte
     // alignment and makes 8-byte accesses of 32 consecutive lanes hit 64 distinct banks.
     __shared__ unsigned lev[NT * TB_LS];
-    // per (day of the block, lane) state byte; every thread touches only its own bytes.  256-thread tiles keep it
-    // in LDS; 1024-thread tiles (LDS is full of level columns) in a global scratch slab, which lifts the limit on Dd
-    __shared__ unsigned char gst_lds[NT > 256 ? 1 : TB_DMAX][NT];
-    unsigned char (*gst)[NT] = gst_lds;
-    if (NT > 256)
-        gst = reinterpret_cast<unsigned char (*)[NT]>(
-            gscratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)Dd * NT);
+    // per (day of the block, lane) state byte in a global scratch slab (every thread touches only its own bytes, a few
+    // per day): keeping it out of LDS lets four 256-thread tiles share a CU and lifts the limit on Dd for the big tiles
+    unsigned char (*gst)[NT] = reinterpret_cast<unsigned char (*)[NT]>(
+        gscratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)Dd * NT);
     __shared__ int s_gmin, s_gmax, s_unres;
     __shared__ unsigned tot_s[NT];  // per tile cell: number of samples in its window (top of the cumulative column)
 
@@ -739,7 +736,7 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
         const int tiles_x = (nx + OC - 1) / OC, tiles_y = (row1 - row0 + OR - 1) / OR;
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((NDOY + Dd - 1) / Dd));
         unsigned char* gscratch = nullptr;
-        if (big) {  // state bytes of the 1024-thread tiles
+        {  // per-(tile, day, lane) state bytes
             const size_t need = (size_t)grid.x * grid.y * (size_t)Dd * NT;
             if (need > ctx->thr_scratch_bytes) {
                 if (ctx->thr_scratch) HIP_TRY(ctx, hipFree(ctx->thr_scratch));
