@@ -240,6 +240,14 @@ int marex_label_mesh_i32(marex_ctx* ctx, const uint8_t* data, const uint8_t* mas
  * -5 malformed frame, -6 unsupported codec / filter. */
 int marex_blosc_decompress_h(const void* src, int64_t srclen, void* dst, int64_t dstcap, int64_t* out_len);
 
+/* Host-side inverse: compress nbytes bytes into one Blosc-1 frame (LZ4 codec; byte shuffle when shuffle != 0 and
+ * typesize > 1; blocksize <= 0 = 256 KiB) -- the chunk format `extremes_ds.to_zarr(...)` produces through numcodecs'
+ * default compressor (examples/batch jobs/run_detect.py:83).  Blocks are split into `typesize` streams exactly when every
+ * c-blosc 1.x decoder expects it; incompressible streams / frames are stored, so dstcap >= nbytes + 16 always suffices.
+ * 0 = OK and *out_len = frame bytes; -1 bad argument, -4 destination too small. */
+int marex_blosc_compress_h(const void* src, int64_t nbytes, int typesize, int shuffle, int64_t blocksize, void* dst,
+                           int64_t dstcap, int64_t* out_len);
+
 /* Device-side chunk decoding (compressed bytes cross PCIe, the field is born in HBM): n_streams LZ4 block streams --
  * stream s = comp[src_off[s] .. +csize[s]) -> planes[dst_off[s] .. +rawsz[s]) (csize == rawsz: stored, copied) -- one
  * wave each; *status (device int, zeroed by the caller) counts malformed streams.  Then marex_unshuffle_place turns the

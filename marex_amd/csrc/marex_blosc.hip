@@ -51,8 +51,170 @@ long lz4_block_decode(const unsigned char* src, long srclen, unsigned char* dst,
 }
 
 inline unsigned rd32(const unsigned char* p) { return (unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | ((unsigned)p[3] << 24); }
+inline void wr32(unsigned char* p, unsigned v) {
+    p[0] = (unsigned char)v;
+    p[1] = (unsigned char)(v >> 8);
+    p[2] = (unsigned char)(v >> 16);
+    p[3] = (unsigned char)(v >> 24);
+}
+
+// Blosc splits a block into `typesize` streams when this holds (c-blosc 1.x blosc_d, also the rule of the releases
+// that predate the "dont_split" flag -- frames written this way decode everywhere)
+inline bool blosc_splits(unsigned flags, long typesize, long blocksize, bool leftover) {
+    return !(flags & 0x10) && !leftover && typesize <= 16 && blocksize / typesize >= 128;
+}
+
+// LZ4 block compressor: greedy, one hash probe per position, matches extended eight bytes at a time.  Honours the
+// format's end-of-block rules (the last match starts at least 12 bytes before the end, the last 5 bytes are
+// literals).  Returns the compressed size, or -1 when the output would not fit in `cap` bytes.
+long lz4_block_encode(const unsigned char* src, long n, unsigned char* dst, long cap) {
+    constexpr int HLOG = 13;
+    int table[1 << HLOG];
+    for (int i = 0; i < (1 << HLOG); ++i) table[i] = -1;
+    unsigned char* op = dst;
+    unsigned char* const oend = dst + cap;
+    long anchor = 0, ip = 0;
+    auto emit = [&](long lit, long mlen, long offset) -> bool {  // mlen == 0: final literals
+        const long need = 1 + lit / 255 + 1 + lit + (mlen ? 2 + mlen / 255 + 1 : 0);
+        if (need > oend - op) return false;
+        unsigned char* token = op++;
+        *token = (unsigned char)((lit < 15 ? lit : 15) << 4);
+        if (lit >= 15) {
+            long r = lit - 15;
+            for (; r >= 255; r -= 255) *op++ = 255;
+            *op++ = (unsigned char)r;
+        }
+        memcpy(op, src + anchor, (size_t)lit);
+        op += lit;
+        if (mlen) {
+            *op++ = (unsigned char)offset;
+            *op++ = (unsigned char)(offset >> 8);
+            const long m = mlen - 4;
+            *token |= (unsigned char)(m < 15 ? m : 15);
+            if (m >= 15) {
+                long r = m - 15;
+                for (; r >= 255; r -= 255) *op++ = 255;
+                *op++ = (unsigned char)r;
+            }
+        }
+        return true;
+    };
+    if (n >= 13) {
+        const long mflimit = n - 12, matchlimit = n - 5;
+        long misses = 0;
+        while (ip <= mflimit) {
+            const unsigned v = rd32(src + ip);
+            const unsigned h = (v * 2654435761u) >> (32 - HLOG);
+            const long cand = table[h];
+            table[h] = (int)ip;
+            if (cand < 0 || ip - cand > 65535 || rd32(src + cand) != v) {
+                ip += 1 + (misses++ >> 6);  // incompressible stretches: widen the step
+                continue;
+            }
+            misses = 0;
+            long s = ip, c = cand;
+            while (s > anchor && c > 0 && src[s - 1] == src[c - 1]) {  // extend backwards over pending literals
+                --s;
+                --c;
+            }
+            long e = ip + 4, ce = cand + 4;
+            while (e + 8 <= matchlimit) {
+                unsigned long long a, b;
+                memcpy(&a, src + e, 8);
+                memcpy(&b, src + ce, 8);
+                if (a != b) {
+                    const long same = __builtin_ctzll(a ^ b) >> 3;
+                    e += same;
+                    ce += same;
+                    goto extended;
+                }
+                e += 8;
+                ce += 8;
+            }
+            while (e < matchlimit && src[e] == src[ce]) {
+                ++e;
+                ++ce;
+            }
+        extended:
+            if (!emit(s - anchor, e - s, s - c)) return -1;
+            anchor = ip = e;
+            if (ip - 2 > cand && ip - 2 <= mflimit) table[(rd32(src + ip - 2) * 2654435761u) >> (32 - HLOG)] = (int)(ip - 2);
+        }
+    }
+    if (!emit(n - anchor, 0, 0)) return -1;
+    return (long)(op - dst);
+}
 
 }  // namespace
+
+// Compress `nbytes` bytes into one Blosc-1 frame (LZ4 codec, byte shuffle when shuffle != 0 and typesize > 1) -- what the
+// reference's `Dataset.to_zarr` writes through numcodecs' default Blosc compressor.  blocksize <= 0 picks 256 KiB.  Data
+// that LZ4 cannot shrink is stored (per stream, or the whole frame as a "memcpyed" frame), so dstcap >= nbytes + 16 always
+// suffices.  0 = OK and *out_len = frame bytes; -1 bad argument, -4 destination too small.
+extern "C" int marex_blosc_compress_h(const void* src_v, int64_t nbytes, int typesize, int shuffle, int64_t blocksize,
+                                      void* dst_v, int64_t dstcap, int64_t* out_len) {
+    if (!src_v || !dst_v || !out_len || nbytes < 0 || nbytes > 0x7fffffff - 16 || typesize < 1) return -1;
+    if (dstcap < nbytes + 16) return -4;
+    if (typesize > 255) typesize = 1;  // as Blosc: such items are treated as bytes
+    const unsigned char* src = static_cast<const unsigned char*>(src_v);
+    unsigned char* dst = static_cast<unsigned char*>(dst_v);
+    if (blocksize <= 0) blocksize = 256 * 1024;
+    if (blocksize > nbytes && nbytes > 0) blocksize = nbytes;
+    if (blocksize > typesize) blocksize -= blocksize % typesize;  // whole elements per block; a ragged tail becomes the leftover block
+    const bool do_shuffle = shuffle && typesize > 1;
+    unsigned flags = (1u << 5) | (do_shuffle ? 0x1u : 0u);
+    dst[0] = 2;  // Blosc format version
+    dst[1] = 1;  // LZ4 format version
+    dst[3] = (unsigned char)typesize;
+    wr32(dst + 4, (unsigned)nbytes);
+    wr32(dst + 8, (unsigned)blocksize);
+    auto stored_frame = [&]() {
+        dst[2] = (unsigned char)(flags | 0x2u);
+        memcpy(dst + 16, src, (size_t)nbytes);
+        wr32(dst + 12, (unsigned)(nbytes + 16));
+        *out_len = nbytes + 16;
+        return 0;
+    };
+    if (nbytes == 0) return stored_frame();
+    const long nblocks = (long)((nbytes + blocksize - 1) / blocksize);
+    long pos = 16 + 4 * nblocks;
+    if (pos >= dstcap) return stored_frame();
+    std::vector<unsigned char> tmp(do_shuffle ? (size_t)blocksize : 0);
+    for (long j = 0; j < nblocks; ++j) {
+        const long bsize = (j == nblocks - 1 && nbytes % blocksize) ? (long)(nbytes % blocksize) : (long)blocksize;
+        const bool leftover = bsize != blocksize;
+        const unsigned char* in = src + j * blocksize;
+        if (do_shuffle) {  // plane k holds byte k of every element; a tail shorter than one element is copied
+            const long ne = bsize / typesize;
+            for (long k = 0; k < typesize; ++k) {
+                unsigned char* plane = tmp.data() + k * ne;
+                for (long i = 0; i < ne; ++i) plane[i] = in[i * typesize + k];
+            }
+            const long rest = bsize - ne * typesize;
+            if (rest) memcpy(tmp.data() + ne * typesize, in + ne * typesize, (size_t)rest);
+            in = tmp.data();
+        }
+        const long nsplits = blosc_splits(flags, typesize, (long)blocksize, leftover) && bsize % typesize == 0 ? typesize : 1;
+        const long neblock = bsize / nsplits;
+        wr32(dst + 16 + 4 * j, (unsigned)pos);
+        for (long s = 0; s < nsplits; ++s) {
+            // the frame may not grow past nbytes + 16: a stream that does not fit is the signal to store everything
+            const long room = (long)(nbytes + 16) - pos - 4;
+            long cb = room > 0 ? lz4_block_encode(in + s * neblock, neblock, dst + pos + 4, room < neblock - 1 ? room : neblock - 1) : -1;
+            if (cb < 0) {  // not compressible: stored stream, marked by cbytes == raw size
+                if (neblock > room) return stored_frame();
+                memcpy(dst + pos + 4, in + s * neblock, (size_t)neblock);
+                cb = neblock;
+            }
+            wr32(dst + pos, (unsigned)cb);
+            pos += 4 + cb;
+        }
+    }
+    dst[2] = (unsigned char)flags;
+    wr32(dst + 12, (unsigned)pos);
+    *out_len = pos;
+    return 0;
+}
 
 // Decompress one Blosc-1 frame.  Returns 0 and the decoded size in *out_len, or a negative code:
 //  -1 bad argument, -5 malformed frame, -6 unsupported codec / filter (anything but LZ4 or memcpy, byte shuffle or none)
@@ -76,14 +238,13 @@ extern "C" int marex_blosc_decompress_h(const void* src_v, int64_t srclen, void*
     if (codec != 1) return -6;
     if (blocksize <= 0) return -5;
     const bool shuffle = (flags & 0x1) && typesize > 1;
-    const bool dont_split = (flags & 0x10) != 0;
     const long nblocks = (nbytes + blocksize - 1) / blocksize;
     if (16 + 4 * nblocks > srclen) return -5;
     std::vector<unsigned char> tmp((size_t)blocksize);
     for (long j = 0; j < nblocks; ++j) {
         const long bsize = (j == nblocks - 1 && nbytes % blocksize) ? nbytes % blocksize : blocksize;
         const bool leftover = bsize != blocksize;
-        const long nsplits = (!dont_split && !leftover && typesize <= 16 && bsize % typesize == 0) ? typesize : 1;
+        const long nsplits = (blosc_splits(flags, typesize, blocksize, leftover) && bsize % typesize == 0) ? typesize : 1;
         const long neblock = bsize / nsplits;
         long pos = rd32(src + 16 + 4 * j);
         unsigned char* out = shuffle ? tmp.data() : dst + j * blocksize;

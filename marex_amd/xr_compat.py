@@ -191,6 +191,14 @@ class _MiniDataset:
 
     sizes = dims
 
+    def to_zarr(self, store, mode: str = "w", chunks=None, **_ignored):
+        """``Dataset.to_zarr`` as the reference's batch script calls it (examples/batch jobs/run_detect.py:83)."""
+        from .zarr_io import write_dataset
+
+        if mode not in ("w", "w-"):
+            raise ValueError("the stand-in Dataset writes whole stores only (mode='w')")
+        write_dataset(str(store), self, chunks)
+
     def __repr__(self):  # pragma: no cover
         return f"<marex_amd.Dataset vars={list(self.data_vars)} attrs={list(self.attrs)}>"
 

@@ -1,7 +1,9 @@
-"""Minimal Zarr v2 reader for the stores the reference writes and tests with (first step): directory
-store, C order, ``.`` chunk keys, Blosc-1 / LZ4 / byte-shuffle chunks decoded by ``marex_blosc_decompress_h`` (host side of
-the C ABI).  Enough to run the hot path on ``tests/data/*.zarr`` of the reference; zstd-compressed coordinate arrays and
-writing are not covered."""
+"""Minimal Zarr v2 reader / writer for the stores the reference reads, writes and tests with: directory
+store, C order, ``.`` chunk keys, consolidated metadata, Blosc-1 / LZ4 / byte-shuffle chunks encoded and decoded by
+``marex_blosc_compress_h`` / ``marex_blosc_decompress_h`` (host side of the C ABI) or, for reading time-chunked arrays,
+decoded in HBM.  Enough to run the hot path on ``tests/data/*.zarr`` of the reference and to write its result the way
+``extremes_ds.to_zarr(...)`` does (examples/batch jobs/run_detect.py:55-83); Blosc frames with another inner codec (the
+zstd-compressed lat / lon arrays of ``sst_gridded.zarr``) are not decoded."""
 from __future__ import annotations
 
 import ctypes as C
@@ -115,7 +117,7 @@ def read_array_to_device(path: str, eng, lead: int | None = None):
         for j in range(nblocks):
             bsize = nbytes - j * blocksize if j == nblocks - 1 else blocksize
             leftover = bsize != blocksize
-            nsplits = ts if (not (flags & 0x10) and not leftover and ts <= 16 and bsize % ts == 0) else 1
+            nsplits = ts if (not (flags & 0x10) and not leftover and ts <= 16 and blocksize // ts >= 128 and bsize % ts == 0) else 1
             neblock = bsize // nsplits
             p = bstarts[j]
             for s in range(nsplits):
@@ -154,7 +156,7 @@ def read_array_to_device(path: str, eng, lead: int | None = None):
     if int(status.item()) != 0:
         raise DataValidationError("malformed LZ4 stream in a chunk", details=f"{int(status.item())} streams failed")
     tdt = {"float32": torch.float32, "float64": torch.float64, "int32": torch.int32, "int64": torch.int64, "int8": torch.int8,
-           "uint8": torch.uint8, "int16": torch.int16}[dtype.name]
+           "uint8": torch.uint8, "int16": torch.int16, "bool": torch.bool}[dtype.name]
     return out.view(tdt).reshape((T,) + shape[1:])
 
 
@@ -198,3 +200,171 @@ def open_dataarray_device(store: str, variable: str, eng, dims, time_var: str = 
     c = {dims[0]: tm}
     c.update(coords or {})
     return DeviceDataArray(x, dims, c, name=variable, attrs=array_attrs(os.path.join(store, variable)))
+
+
+# ------------------------------------------------------------------------------------------------
+# writing (examples/batch jobs/run_detect.py:83: ``extremes_ds.to_zarr(output_file, mode="w")``)
+# ------------------------------------------------------------------------------------------------
+_BLOSC_LZ4 = {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0}  # numcodecs' / xarray's default
+
+
+def _compress(buf, typesize: int) -> bytes:
+    lib = _lib.load()
+    src = np.ascontiguousarray(buf).view(np.uint8).reshape(-1)
+    out = np.empty(src.size + 16, dtype=np.uint8)
+    n = C.c_int64(0)
+    rc = lib.marex_blosc_compress_h(src.ctypes.data, src.size, typesize, 1, 0, out.ctypes.data, out.size, C.byref(n))
+    if rc != 0:
+        raise DataValidationError("Blosc compression failed", details=f"code {rc}, {src.size} bytes")
+    return out[: n.value].tobytes()
+
+
+def _zarr_dtype(dt: np.dtype) -> str:
+    dt = np.dtype(dt)
+    if dt == np.bool_:
+        return "|b1"
+    if dt.kind not in "fiu" or dt.byteorder == ">":
+        raise DependencyError(f"unsupported dtype {dt} (little-endian float / int / bool arrays are written)")
+    return dt.str if dt.itemsize > 1 else "|" + dt.str[1:]
+
+
+def _json_attr(v):
+    if isinstance(v, np.generic):
+        return v.item()
+    if isinstance(v, np.ndarray):
+        return v.tolist()
+    if isinstance(v, (list, tuple)):
+        return [_json_attr(x) for x in v]
+    if isinstance(v, dict):
+        return {str(k): _json_attr(x) for k, x in v.items()}
+    return v
+
+
+def write_array(path: str, data, chunks=None, dims=None, attrs=None, compress: bool = True, threads: int = 8) -> Dict:
+    """Write one Zarr v2 array directory.  ``data`` is a NumPy array or a torch tensor (host or device; a device tensor
+    is brought over one chunk of its first dimension at a time, so a field that fills HBM never needs a host copy of
+    itself).  ``chunks`` defaults to the whole array; chunks are compressed by a small thread pool (the C call releases the
+    GIL).  Returns ``{".zarray": ..., ".zattrs": ...}`` for the consolidated metadata."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    is_torch = hasattr(data, "device") and hasattr(data, "cpu")
+    shape = tuple(int(n) for n in data.shape)
+    dtype = np.dtype(str(data.dtype).replace("torch.", "")) if is_torch else np.dtype(data.dtype)
+    zdtype = _zarr_dtype(dtype)
+    chunks = tuple(int(min(max(c, 1), max(n, 1))) for c, n in zip(shape if chunks is None else chunks, shape))
+    if len(chunks) != len(shape):
+        raise DataValidationError("chunks do not match the array rank", details=f"shape {shape}, chunks {chunks}")
+    os.makedirs(path, exist_ok=True)
+    fill = "NaN" if dtype.kind == "f" else None  # what xarray writes (see the reference's stores)
+    zarray = {"zarr_format": 2, "shape": list(shape), "chunks": list(chunks), "dtype": zdtype, "order": "C", "filters": None,
+              "fill_value": fill, "compressor": dict(_BLOSC_LZ4) if compress else None}
+    zattrs = {k: _json_attr(v) for k, v in (attrs or {}).items()}
+    if dims is not None:
+        zattrs["_ARRAY_DIMENSIONS"] = list(dims)  # xarray's convention for naming Zarr dimensions
+    json.dump(zarray, open(os.path.join(path, ".zarray"), "w"), indent=1)
+    json.dump(zattrs, open(os.path.join(path, ".zattrs"), "w"), indent=1)
+
+    def slab(i0):  # host copy of rows [i0*c0, (i0+1)*c0) of the first dimension
+        if not shape:
+            return np.asarray(data.cpu().numpy() if is_torch else data).reshape(())
+        part = data[i0 * chunks[0]: (i0 + 1) * chunks[0]]
+        return part.cpu().numpy() if is_torch else np.asarray(part)
+
+    def put(idx, block):
+        full = np.zeros(chunks, dtype=dtype) if block.shape != chunks else block  # edge chunks are padded to full size
+        if full is not block:
+            if dtype.kind == "f":
+                full[...] = np.nan
+            full[tuple(slice(0, n) for n in block.shape)] = block
+        raw = np.ascontiguousarray(full)
+        payload = _compress(raw, dtype.itemsize) if compress else raw.tobytes()
+        name = ".".join(str(i) for i in idx) if idx else "0"
+        with open(os.path.join(path, name), "wb") as f:
+            f.write(payload)
+
+    grid = [range((n + c - 1) // c) for n, c in zip(shape, chunks)]
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+        for i0 in (grid[0] if shape else [0]):
+            part = slab(i0)
+            jobs = []
+            for rest in itertools.product(*grid[1:]):
+                sel = tuple(slice(j * c, min((j + 1) * c, n)) for j, c, n in zip(rest, chunks[1:], shape[1:]))
+                block = part[(slice(None),) + sel] if shape else part
+                jobs.append(pool.submit(put, ((i0,) + rest) if shape else (), block))
+            for j in jobs:
+                j.result()
+    return {".zarray": zarray, ".zattrs": zattrs}
+
+
+def encode_cf_time(values) -> tuple:
+    """datetime64 axis -> (int64 ``days since`` the first day, CF attrs): the encoding xarray picks for a daily axis."""
+    t = np.asarray(values).astype("datetime64[D]")
+    t0 = t[0] if t.size else np.datetime64("1970-01-01")
+    return (t - t0).astype(np.int64), {"units": f"days since {t0} 00:00:00", "calendar": "proleptic_gregorian"}
+
+
+def write_dataset(store: str, ds, chunks: Dict[str, int] | None = None, compress: bool = True, threads: int = 8) -> None:
+    """``ds.to_zarr(store, mode="w")`` for the Dataset ``preprocess_data`` returns (stand-in or device-resident variables):
+    every data variable and coordinate becomes an array directory, attributes go to ``.zattrs``, and ``.zmetadata`` holds
+    the consolidated copy that ``xr.open_zarr`` reads first.  ``chunks`` maps dimension names to chunk lengths (default:
+    ``time`` in steps of 25 -- the reference's output chunking, detect.py:785-792 -- everything else whole)."""
+    import shutil
+
+    chunks = dict({"time": 25}, **(chunks or {}))
+    if os.path.isdir(store):
+        shutil.rmtree(store)  # mode="w"
+    os.makedirs(store)
+    meta = {".zgroup": {"zarr_format": 2}, ".zattrs": {k: _json_attr(v) for k, v in getattr(ds, "attrs", {}).items()}}
+    json.dump(meta[".zgroup"], open(os.path.join(store, ".zgroup"), "w"))
+    json.dump(meta[".zattrs"], open(os.path.join(store, ".zattrs"), "w"), indent=1)
+    coord_names = list(ds.coords)
+    items = [(k, ds.coords[k], True) for k in coord_names] + [(k, v, False) for k, v in ds.data_vars.items()]
+    for name, var, is_coord in items:
+        data = getattr(var, "device_tensor", None)
+        if data is None:
+            data = var.data if hasattr(var, "data") else var.values
+        attrs = dict(getattr(var, "attrs", {}))
+        dims = tuple(var.dims)
+        if not hasattr(data, "cpu") and np.asarray(data).dtype.kind == "M":
+            data, tattrs = encode_cf_time(np.asarray(data))
+            attrs.update(tattrs)
+        if not is_coord:
+            aux = [c for c in coord_names if c not in dims and set(ds.coords[c].dims) <= set(dims) and ds.coords[c].dims]
+            if aux:
+                attrs["coordinates"] = " ".join(aux)  # non-index coordinates (lat / lon of an unstructured mesh)
+        ch = None if is_coord else tuple(chunks.get(d, n) for d, n in zip(dims, data.shape))
+        m = write_array(os.path.join(store, name), data, ch, dims, attrs, compress, threads)
+        meta[f"{name}/.zarray"] = m[".zarray"]
+        meta[f"{name}/.zattrs"] = m[".zattrs"]
+    json.dump({"zarr_consolidated_format": 1, "metadata": meta}, open(os.path.join(store, ".zmetadata"), "w"), indent=1)
+
+
+def read_dataset(store: str):
+    """``xr.open_zarr(store)`` into the stand-in Dataset (host arrays): variables named like one of their own dimensions
+    are coordinates, ``_ARRAY_DIMENSIONS`` names the dimensions, CF time axes are decoded."""
+    from .xr_compat import _MiniDataArray, _MiniDataset
+
+    names = sorted(d for d in os.listdir(store) if os.path.exists(os.path.join(store, d, ".zarray")))
+    arrays = {}
+    for n in names:
+        p = os.path.join(store, n)
+        at = array_attrs(p)
+        v = read_array(p)
+        dims = tuple(at.pop("_ARRAY_DIMENSIONS", [f"dim_{i}" for i in range(v.ndim)]))
+        if " since " in str(at.get("units", "")):
+            v = decode_cf_time(v, at)
+            at.pop("units", None)
+            at.pop("calendar", None)
+        if json.load(open(os.path.join(p, ".zarray")))["dtype"] == "|b1":
+            v = v.astype(bool)
+        arrays[n] = (dims, v, at)
+    aux = set()
+    for dims, v, at in arrays.values():
+        aux.update(str(at.pop("coordinates", "")).split())
+    coords = {n: _MiniDataArray(v, d, None, n, at) for n, (d, v, at) in arrays.items() if d == (n,) or n in aux}
+    gattrs = array_attrs(store)
+    ds = _MiniDataset(None, coords, gattrs)
+    for n, (d, v, at) in arrays.items():
+        if n not in coords:
+            ds[n] = _MiniDataArray(v, d, {c: coords[c] for c in coords if set(coords[c].dims) <= set(d)}, n, at)
+    return ds

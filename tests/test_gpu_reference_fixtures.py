@@ -124,6 +124,31 @@ def test_preprocess_straight_from_the_compressed_store(hot, sst):
     assert np.array_equal(a.dat_anomaly.coords["time"].values, b.dat_anomaly.coords["time"].values)
 
 
+def test_result_written_like_the_reference_and_read_back_in_hbm(hot, sst, tmp_path):
+    """examples/batch jobs/run_detect.py:60-83: preprocess_data(...).to_zarr(store); the store is then the tracker's input.
+    Chunks our writer compressed decode on the device (one wave per LZ4 stream) to the arrays that were written, and a
+    device tensor is written chunk by chunk without a host copy of the whole array."""
+    import torch
+
+    da_host, _ = sst
+    ds = marex_amd.preprocess_data(da_host, method_anomaly="shifting_baseline", method_extreme="hobday_extreme",
+                                   threshold_percentile=95, window_year_baseline=5, smooth_days_baseline=11, window_days_hobday=3)
+    store = str(tmp_path / "extremes.zarr")
+    ds.to_zarr(store, mode="w")
+    back = zarr_io.read_dataset(store)
+    for v in ("dat_anomaly", "extreme_events", "thresholds", "mask"):
+        assert back[v].dims == ds[v].dims and back[v].values.dtype == ds[v].values.dtype
+        assert np.array_equal(back[v].values, ds[v].values, equal_nan=True), v
+    assert np.array_equal(back.time.values.astype("datetime64[D]"), ds.dat_anomaly.coords["time"].values.astype("datetime64[D]"))
+    assert back.attrs["method_anomaly"] == "shifting_baseline"
+    for v in ("dat_anomaly", "extreme_events"):
+        dev = zarr_io.read_array_to_device(os.path.join(store, v), hot)
+        assert np.array_equal(dev.cpu().numpy().astype(ds[v].values.dtype), ds[v].values, equal_nan=True), v
+    t = torch.from_numpy(ds.dat_anomaly.values).to(hot.device)
+    zarr_io.write_array(os.path.join(store, "from_device"), t, (25,) + tuple(t.shape[1:]), dims=ds.dat_anomaly.dims)
+    assert np.array_equal(zarr_io.read_array(os.path.join(store, "from_device")), ds.dat_anomaly.values, equal_nan=True)
+
+
 @pytest.fixture(scope="module")
 def sst_unstructured():
     p = os.path.join(FIX, "sst_unstructured.zarr")
