@@ -178,6 +178,11 @@ class _Field:
             return self._x_dev.to(device=eng.device, dtype=torch.float32).contiguous()
         return torch.from_numpy(self.x).to(eng.device)
 
+    def block(self, sh) -> "_FieldBlock":
+        """The cells a spatial block ingests (``marex_amd.dist.Shard``): a latitude band with its overlap rows, or a range of
+        cells -- contiguous on the cell axis either way."""
+        return _FieldBlock(self, sh)
+
     def labelled(self, data: np.ndarray, lead: Optional[Tuple[str, np.ndarray]], trail: Optional[Tuple[str, np.ndarray]] = None):
         """Wrap ``data`` with dims ``(lead?, *spatial, trail?)``; ``data``'s cell axis is still flat."""
         dims, coords, shape = [], {}, []
@@ -189,6 +194,56 @@ class _Field:
             dims.append(trail[0]); coords[trail[0]] = trail[1]; shape.append(len(trail[1]))
         coords.update(self.scoords)
         return DataArray(np.asarray(data).reshape(shape), dims=dims, coords=coords)
+
+
+class _FieldBlock:
+    """What the device stages read of a ``_Field``, restricted to one spatial block."""
+
+    def __init__(self, field: _Field, sh):
+        self.parent, self.shard = field, sh
+        self.c0, self.c1 = sh.cell_base, sh.cell_base + sh.cells_in
+        self.time, self.gridded = field.time, field.gridded
+        self.ny, self.nx = (sh.ny_in, field.nx) if field.gridded else (0, sh.cells_in)
+        self.shape = (field.shape[0], sh.cells_in)
+
+    def device_x(self, eng):
+        import torch
+
+        f = self.parent
+        if f._x_dev is not None:
+            return f._x_dev[:, self.c0:self.c1].to(device=eng.device, dtype=torch.float32).contiguous()
+        return torch.from_numpy(f.x[:, self.c0:self.c1]).to(eng.device).contiguous()
+
+
+def plan_blocks(field: _Field, eng, halo: int, per_cell_bytes: int):
+    """Spatial blocks that fit the free HBM -- the device-side counterpart of the reference's Dask layout for this path
+    (space chunked, ``time: -1``; detect.py:2617-2620, 785-792): latitude bands with ``halo`` overlap rows per interior
+    side on grids, cell ranges on meshes.  ``MAREX_BLOCKS=n`` forces the number of blocks (tests; tuning)."""
+    import os
+
+    import torch
+
+    from .dist import plan_shards
+
+    ny, nx = (field.ny, field.nx) if field.gridded else (0, field.nx)
+    forced = int(os.environ.get("MAREX_BLOCKS", "0"))
+    if forced > 0:
+        n = min(forced, ny if field.gridded else max(nx, 1))
+        return plan_shards(ny, nx, max(n, 1), halo)
+    if eng.device.type != "cuda":
+        return plan_shards(ny, nx, 1, halo)
+    torch.cuda.empty_cache()
+    budget = int(torch.cuda.mem_get_info(eng.device)[0] * 0.8)
+    n = 1
+    while True:
+        shards = plan_shards(ny, nx, n, halo)
+        if max(sh.cells_in for sh in shards) * per_cell_bytes <= budget:
+            return shards
+        if n >= (ny if field.gridded else nx):
+            raise create_data_validation_error(
+                "Field does not fit the device even one latitude row / cell at a time",
+                details=f"{per_cell_bytes} bytes per cell, {budget} bytes of HBM free")
+        n = min(max(n + 1, int(n * 1.25)), ny if field.gridded else nx)
 
 
 def _raise_if_invalid(field: _Field, summary: Dict[str, int]) -> None:
@@ -417,11 +472,12 @@ def _anomaly_core(eng, field: _Field, method_anomaly, window_year_baseline, smoo
     return {"anom": r["out"], "mask": r["mask"], "invalid": r["invalid_count"], "bins": r.get("bins"), "cal": cal, "dcal": dcal}
 
 
-def _validation_summary(a) -> Dict[str, int]:
+def _validation_summary(a, own: Optional[slice] = None) -> Dict[str, int]:
     import torch
 
-    m = a["mask"].to(torch.int32)
-    inv = a["invalid"] * m
+    own = slice(None) if own is None else own
+    m = a["mask"][own].to(torch.int32)
+    inv = a["invalid"][own] * m
     return {
         "n_ocean": int(m.sum().item()),
         "invalid_total": int(inv.sum().item()),
@@ -447,14 +503,25 @@ def _warn_threshold_range(stats: Dict[str, float], bt: binning.BinTable, max_ano
         )
 
 
-def _extremes_core(eng, a, field: _Field, method_extreme, threshold_percentile, window_days_hobday, ws_eff,
-                   method_percentile, bt: Optional[binning.BinTable], max_anomaly, wsp=None):
-    """Threshold + mask stage on the device.  Returns (extreme uint8 [T', C], thresholds (host layout), dims tag)."""
+def _extremes_core(eng, a, field, method_extreme, threshold_percentile, window_days_hobday, ws_eff,
+                   method_percentile, bt: Optional[binning.BinTable], max_anomaly, wsp=None, rows=None, defer=None):
+    """Threshold + mask stage on the device.  Returns (extreme uint8 [T', C], thresholds (host layout), dims tag).
+    ``rows``: grid rows of a latitude band whose thresholds are wanted (the others are overlap rows); ``defer``: a dict
+    that collects the threshold-range statistics instead of warning at once (block-wise runs warn once, at the end)."""
     cal, dcal = a["cal"], a["dcal"]
+
+    def range_stats(stats, table):
+        if defer is None:
+            _warn_threshold_range(stats, table, max_anomaly)
+        else:
+            defer["stats"].append((stats, table))
+
     if method_extreme == "hobday_extreme":
         n_years = cal.n_years_present if cal.T_out == cal.T else int(np.unique(cal.year[cal.kept]).size)
         n_above = n_years * window_days_hobday * (ws_eff if ws_eff is not None else 1) ** 2 * (1.0 - threshold_percentile / 100.0)
-        if n_above < 50:  # detect.py:1905-1915
+        if n_above < 50 and not (defer or {}).get("logged"):  # detect.py:1905-1915
+            if defer is not None:
+                defer["logged"] = True
             logger.warning(
                 f"Not enough samples for accurate extreme detection: {n_above} < 50. "
                 "Consider using a lower threshold_percentile, increasing your time-series size, "
@@ -466,16 +533,16 @@ def _extremes_core(eng, a, field: _Field, method_extreme, threshold_percentile, 
             return m["extreme"], thr_doy, "doy_first", m["n_true"]
         t = eng.hobday_thresholds(
             a["bins"], a["anom"], dcal, bt, threshold_percentile / 100.0, int(window_days_hobday),
-            int(ws_eff) if ws_eff else 1, field.ny, field.nx,
+            int(ws_eff) if ws_eff else 1, field.ny, field.nx, rows=rows,
         )
         m = eng.mask_ge_doy(a["anom"], t["thr_doy_major"], dcal)
         thr = eng.transpose(t["thr_doy_major"])
-        _warn_threshold_range(eng.decode_thr_stats(t["stats_dev"]), bt, max_anomaly)
+        range_stats(eng.decode_thr_stats(t["stats_dev"]), bt)
         return m["extreme"], thr, "doy_last", m["n_true"]
     # global_extreme
     g = eng.global_threshold(a["anom"], float(threshold_percentile), method_percentile, bt)
     if method_percentile == "approximate":
-        _warn_threshold_range(g["stats"], binning.global_bins(bt.precision, bt.max_anomaly), max_anomaly)
+        range_stats(g["stats"], binning.global_bins(bt.precision, bt.max_anomaly))
     m = eng.mask_ge_const(a["anom"], g["thr_f64"])
     return m["extreme"], g["thr_f64"], "none", m["n_true"]
 
@@ -545,58 +612,119 @@ def preprocess_data(
     eng = get_engine(device)
     bt = binning.hobday_bins(precision, max_anomaly) if method_percentile == "approximate" else None
     need_bins = bt if (method_extreme == "hobday_extreme" and method_percentile == "approximate") else None
+    want_stn = bool(std_normalise) and method_anomaly == "detrend_harmonic"
 
-    a = _anomaly_core(eng, field, method_anomaly, window_year_baseline, smooth_days_baseline, detrend_orders,
-                      force_zero_mean, reference_period, need_bins)
-    _raise_if_invalid(field, _validation_summary(a))
-    cal = a["cal"]
+    # Spatial blocks sized to the free HBM (one block when everything fits): every stage is per cell along time except
+    # the ws x ws pooling, so latitude bands carry ws//2 overlap rows and nothing is exchanged between blocks.
+    T = field.shape[0]
+    halo = (int(ws_eff) // 2) if (need_bins is not None and ws_eff) else 0
+    per_cell = (4 * T + 7 * T) + (8 * T if method_anomaly.startswith("detrend") else 0) + (11 * T if want_stn else 0) + 366 * 24
+    blocks = plan_blocks(field, eng, halo, int(per_cell * 1.25))
+    single = len(blocks) == 1
+    if not single:
+        logger.info(f"Field processed in {len(blocks)} spatial blocks of <= {max(b.cells_in for b in blocks)} cells")
+
+    out: Dict[str, np.ndarray] = {}
+    kinds: Dict[str, str] = {}
+    defer = {"stats": [], "logged": False}
+    total = {"n_ocean": 0, "invalid_total": 0, "invalid_cells": 0, "max_invalid": 0}
+    n_true_total, cal = 0, None
+    doy_axis = ("dayofyear", np.arange(1, calendar.N_DOY + 1))
+    C_all = field.shape[1]
+
+    def put(name, t, kind, sh):
+        """Owned cells of a block result -> the host array of the whole field (``kind``: where the cell axis is)."""
+        own = sh.own_cell_slice()
+        g0 = sh.own0 * field.nx if field.gridded else sh.own0
+        axis = {"cells_last": t.ndim - 1, "doy_last": 0, "doy_first": 1, "none": 0}[kind]
+        piece = t[(slice(None),) * axis + (own,)].cpu().numpy()
+        if single:
+            out[name] = piece
+            return
+        if name not in out:
+            shape = list(piece.shape)
+            shape[axis] = C_all
+            out[name] = np.empty(shape, dtype=piece.dtype)
+        out[name][(slice(None),) * axis + (slice(g0, g0 + piece.shape[axis]),)] = piece
+
+    for sh in blocks:
+        fb = field if single else field.block(sh)
+        rows = None if single or not field.gridded else (sh.own0 - sh.in0, sh.own1 - sh.in0)
+        a = _anomaly_core(eng, fb, method_anomaly, window_year_baseline, smooth_days_baseline, detrend_orders,
+                          force_zero_mean, reference_period, need_bins)
+        cal = a["cal"]
+        part = _validation_summary(a, sh.own_cell_slice())
+        for k in ("n_ocean", "invalid_total", "invalid_cells"):
+            total[k] += part[k]
+        total["max_invalid"] = max(total["max_invalid"], part["max_invalid"])
+        if total["max_invalid"] > 0 or (single and total["n_ocean"] == 0):
+            continue  # the run ends in the reference's validation error: only the counts of the other blocks matter
+        ext, thr, thr_kind, n_true = _extremes_core(
+            eng, a, fb, method_extreme, threshold_percentile, window_days_hobday, ws_eff, method_percentile, bt, max_anomaly,
+            rows=rows, defer=defer,
+        )
+        put("dat_anomaly", a["anom"], "cells_last", sh)
+        put("mask", a["mask"], "cells_last", sh)
+        put("extreme_events", ext, "cells_last", sh)
+        put("thresholds", thr, thr_kind, sh)
+        kinds["thresholds"] = thr_kind
+        # standardised anomalies and their own extremes (detect.py:2257-2293, 686-715): detrend_harmonic only
+        if want_stn:
+            if sh is blocks[0]:
+                logger.info("Processing standardised anomalies for extreme identification")
+            sn = eng.std_normalise(a["anom"], a["dcal"])
+            a_stn = {"anom": sn["dat_stn"], "cal": cal, "dcal": a["dcal"], "bins": None}
+            if need_bins is not None:
+                a_stn["bins"] = eng.digitize(sn["dat_stn"], a["dcal"], bt, wsp={})
+            ext_s, thr_s, kind_s, _ = _extremes_core(
+                eng, a_stn, fb, method_extreme, threshold_percentile, window_days_hobday, ws_eff, method_percentile, bt,
+                max_anomaly, wsp={}, rows=rows, defer=defer,
+            )
+            put("dat_stn", sn["dat_stn"], "cells_last", sh)
+            put("STD", eng.transpose(sn["STD"], name="std_cells_major"), "doy_last", sh)  # flox appends the group dim
+            put("extreme_events_stn", ext_s, "cells_last", sh)
+            put("thresholds_stn", thr_s, kind_s, sh)
+            kinds["thresholds_stn"] = kind_s
+        n_true_total += int(n_true.item()) if single else 0
+        eng.sync()
+        del a, ext, thr
+    _raise_if_invalid(field, total)
     if method_anomaly == "shifting_baseline":
         logger.info(f"Trimming data to start from {cal.min_year + window_year_baseline} (removing first {window_year_baseline} years)")
+    # the reference's two threshold-range warnings, once per threshold array (detect.py:2711-2730)
+    per_table: Dict[tuple, list] = {}
+    for st, table in defer["stats"]:
+        per_table.setdefault((table.lower_bound, table.upper_bound), [table, []])[1].append(st)
+    n_arrays = 2 if want_stn else 1
+    for table, sts in per_table.values():
+        per_array = [sts[i::n_arrays] for i in range(n_arrays)] if len(sts) >= n_arrays else [sts]
+        for group in per_array:
+            mx = [g["max"] for g in group if g["max"] == g["max"]]
+            mn = [g["min"] for g in group if g["min"] == g["min"]]
+            _warn_threshold_range({"n_too_high": sum(g["n_too_high"] for g in group), "n_too_low": sum(g["n_too_low"] for g in group),
+                                   "max": max(mx) if mx else float("nan"), "min": min(mn) if mn else float("nan")}, table, max_anomaly)
+    if not single:
+        n_true_total = int(np.count_nonzero(out["extreme_events"]))
 
-    ext, thr, thr_kind, n_true = _extremes_core(
-        eng, a, field, method_extreme, threshold_percentile, window_days_hobday, ws_eff, method_percentile, bt, max_anomaly
-    )
-    # standardised anomalies and their own extremes (detect.py:2257-2293, 686-715): detrend_harmonic only
-    stn = None
-    if std_normalise and method_anomaly == "detrend_harmonic":
-        logger.info("Processing standardised anomalies for extreme identification")
-        sn = eng.std_normalise(a["anom"], a["dcal"])
-        a_stn = {"anom": sn["dat_stn"], "cal": cal, "dcal": a["dcal"], "bins": None}
-        if need_bins is not None:
-            a_stn["bins"] = eng.digitize(sn["dat_stn"], a["dcal"], bt, wsp={})
-        ext_s, thr_s, kind_s, _ = _extremes_core(
-            eng, a_stn, field, method_extreme, threshold_percentile, window_days_hobday, ws_eff, method_percentile, bt,
-            max_anomaly, wsp={},
-        )
-        stn = (sn, ext_s, thr_s, kind_s, eng.transpose(sn["STD"], name="std_cells_major"))
-    eng.sync()
+    def with_doy(name, kind):
+        if kind == "doy_last":
+            return field.labelled(out[name], None, doy_axis)
+        if kind == "doy_first":
+            return field.labelled(out[name], doy_axis)
+        return field.labelled(out[name], None)
 
     time_out = field.time[cal.kept]
     tlead = (field.tdim, time_out)
     ds = Dataset()
-    ds["dat_anomaly"] = field.labelled(a["anom"].cpu().numpy(), tlead)
-    ds["mask"] = field.labelled(a["mask"].cpu().numpy().astype(bool), None)
-    ds["extreme_events"] = field.labelled(ext.cpu().numpy().astype(bool), tlead)
-    doy_axis = ("dayofyear", np.arange(1, calendar.N_DOY + 1))
-    thr_np = thr.cpu().numpy()
-    if thr_kind == "doy_last":
-        ds["thresholds"] = field.labelled(thr_np, None, doy_axis)
-    elif thr_kind == "doy_first":
-        ds["thresholds"] = field.labelled(thr_np, doy_axis)
-    else:
-        ds["thresholds"] = field.labelled(thr_np, None)
-    if stn is not None:
-        sn, ext_s, thr_s, kind_s, std_t = stn
-        ds["dat_stn"] = field.labelled(sn["dat_stn"].cpu().numpy(), tlead)
-        ds["STD"] = field.labelled(std_t.cpu().numpy(), None, doy_axis)  # flox appends the group dim: (*space, dayofyear)
-        ds["extreme_events_stn"] = field.labelled(ext_s.cpu().numpy().astype(bool), tlead)
-        ts_np = thr_s.cpu().numpy()
-        if kind_s == "doy_last":
-            ds["thresholds_stn"] = field.labelled(ts_np, None, doy_axis)
-        elif kind_s == "doy_first":
-            ds["thresholds_stn"] = field.labelled(ts_np, doy_axis)
-        else:
-            ds["thresholds_stn"] = field.labelled(ts_np, None)
+    ds["dat_anomaly"] = field.labelled(out["dat_anomaly"], tlead)
+    ds["mask"] = field.labelled(out["mask"].astype(bool), None)
+    ds["extreme_events"] = field.labelled(out["extreme_events"].astype(bool), tlead)
+    ds["thresholds"] = with_doy("thresholds", kinds["thresholds"])
+    if want_stn:
+        ds["dat_stn"] = field.labelled(out["dat_stn"], tlead)
+        ds["STD"] = with_doy("STD", "doy_last")
+        ds["extreme_events_stn"] = field.labelled(out["extreme_events_stn"].astype(bool), tlead)
+        ds["thresholds_stn"] = with_doy("thresholds_stn", kinds["thresholds_stn"])
     if neighbours is not None:
         ds["neighbours"] = neighbours.astype(np.int32)
     if cell_areas is not None:
@@ -626,7 +754,7 @@ def preprocess_data(
     if method_extreme == "hobday_extreme":
         ds.attrs["window_days_hobday"] = window_days_hobday
     ds.attrs.update({"method_percentile": method_percentile, "precision": precision, "max_anomaly": max_anomaly})
-    logger.info(f"Preprocessing completed successfully - {int(n_true.item())} extreme events identified")
+    logger.info(f"Preprocessing completed successfully - {n_true_total} extreme events identified")
     return ds
 
 
