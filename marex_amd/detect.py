@@ -176,7 +176,7 @@ class _Field:
 
         if self._x_dev is not None:
             return self._x_dev.to(device=eng.device, dtype=torch.float32).contiguous()
-        return torch.from_numpy(self.x).to(eng.device)
+        return _pipe(eng).upload(self.x, np.float32)
 
     def block(self, sh) -> "_FieldBlock":
         """The cells a spatial block ingests (``marex_amd.dist.Shard``): a latitude band with its overlap rows, or a range of
@@ -196,6 +196,15 @@ class _Field:
         return DataArray(np.asarray(data).reshape(shape), dims=dims, coords=coords)
 
 
+def _pipe(eng):
+    """The engine's pinned-buffer transfer pipeline (marex_amd.transfer), created on first use."""
+    if getattr(eng, "_pipe", None) is None:
+        from .transfer import PinnedPipe
+
+        eng._pipe = PinnedPipe(eng.device)
+    return eng._pipe
+
+
 class _FieldBlock:
     """What the device stages read of a ``_Field``, restricted to one spatial block."""
 
@@ -212,7 +221,7 @@ class _FieldBlock:
         f = self.parent
         if f._x_dev is not None:
             return f._x_dev[:, self.c0:self.c1].to(device=eng.device, dtype=torch.float32).contiguous()
-        return torch.from_numpy(f.x[:, self.c0:self.c1]).to(eng.device).contiguous()
+        return _pipe(eng).upload(f.x[:, self.c0:self.c1], np.float32)
 
 
 def plan_blocks(field: _Field, eng, halo: int, per_cell_bytes: int):
@@ -637,15 +646,18 @@ def preprocess_data(
         own = sh.own_cell_slice()
         g0 = sh.own0 * field.nx if field.gridded else sh.own0
         axis = {"cells_last": t.ndim - 1, "doy_last": 0, "doy_first": 1, "none": 0}[kind]
-        piece = t[(slice(None),) * axis + (own,)].cpu().numpy()
-        if single:
-            out[name] = piece
-            return
+        view = t[(slice(None),) * axis + (own,)]
         if name not in out:
-            shape = list(piece.shape)
-            shape[axis] = C_all
-            out[name] = np.empty(shape, dtype=piece.dtype)
-        out[name][(slice(None),) * axis + (slice(g0, g0 + piece.shape[axis]),)] = piece
+            shape = list(view.shape)
+            if not single:
+                shape[axis] = C_all
+            out[name] = np.empty(shape, dtype=np.dtype(str(t.dtype).replace("torch.", "")))
+        dst = out[name] if single else out[name][(slice(None),) * axis + (slice(g0, g0 + view.shape[axis]),)]
+        if view.dim() == 2 and axis == 1 and view.numel() * view.element_size() >= (32 << 20):
+            eng.sync()
+            _pipe(eng).download(view, dst)  # the big [T', cells] arrays: chunked through pinned buffers
+        else:
+            dst[...] = view.cpu().numpy()
 
     for sh in blocks:
         fb = field if single else field.block(sh)
