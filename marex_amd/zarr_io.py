@@ -2,8 +2,8 @@
 store, C order, ``.`` chunk keys, consolidated metadata, Blosc-1 / LZ4 / byte-shuffle chunks encoded and decoded by
 ``marex_blosc_compress_h`` / ``marex_blosc_decompress_h`` (host side of the C ABI) or, for reading time-chunked arrays,
 decoded in HBM.  Enough to run the hot path on ``tests/data/*.zarr`` of the reference and to write its result the way
-``extremes_ds.to_zarr(...)`` does (examples/batch jobs/run_detect.py:55-83); Blosc frames with another inner codec (the
-zstd-compressed lat / lon arrays of ``sst_gridded.zarr``) are not decoded."""
+``extremes_ds.to_zarr(...)`` does (examples/batch jobs/run_detect.py:55-83); the zstd / bit-shuffle frames of small
+coordinate arrays (lat / lon of ``sst_gridded.zarr``) are decoded on the host with pyarrow's zstd codec when it is present."""
 from __future__ import annotations
 
 import ctypes as C
@@ -24,10 +24,55 @@ def _decompress(raw: bytes, nbytes: int) -> bytes:
     n = C.c_int64(0)
     rc = lib.marex_blosc_decompress_h(raw, len(raw), out, nbytes, C.byref(n))
     if rc == -6:
-        raise DependencyError("unsupported Blosc codec or filter (only LZ4 / memcpy with byte shuffle are decoded)")
+        return _decompress_foreign(raw, nbytes)
     if rc != 0 or n.value != nbytes:
         raise DataValidationError("malformed Blosc chunk", details=f"code {rc}, decoded {n.value} of {nbytes} bytes")
     return out.raw
+
+
+def _decompress_foreign(raw: bytes, nbytes: int) -> bytes:
+    """Blosc-1 frames the C decoder declines: an inner zstd codec and / or the bit-shuffle filter (the lat / lon arrays of
+    the reference's ``sst_gridded.zarr``: ``{"cname": "zstd", "shuffle": 2}``).  Small coordinate arrays only -- the frame
+    is parsed here, zstd streams are handed to pyarrow's codec when that package is present, and the bit transpose is
+    undone with NumPy."""
+    import struct
+
+    _, _, flags, typesize, nb, blocksize, cbytes = struct.unpack("<BBBBIII", raw[:16])
+    codec = flags >> 5
+    if codec not in (1, 4) or nb != nbytes or cbytes != len(raw):
+        raise DependencyError("unsupported Blosc codec (LZ4 and zstd frames are decoded)", details=f"flags {flags:#x}")
+    try:
+        import pyarrow as pa
+
+        dec = pa.Codec("zstd" if codec == 4 else "lz4_raw")
+    except Exception as e:  # pragma: no cover
+        raise DependencyError("this Blosc frame needs pyarrow's zstd codec to be decoded", details=str(e))
+    nblocks = (nbytes + blocksize - 1) // blocksize
+    out = bytearray()
+    for j in range(nblocks):
+        bsize = nbytes - j * blocksize if j == nblocks - 1 else blocksize
+        leftover = bsize != blocksize
+        nsplits = typesize if (not flags & 0x10 and not leftover and typesize <= 16 and blocksize // typesize >= 128) else 1
+        ne = bsize // nsplits
+        (p,) = struct.unpack("<i", raw[16 + 4 * j: 20 + 4 * j])
+        blk = bytearray()
+        for _ in range(nsplits):
+            (cb,) = struct.unpack("<i", raw[p: p + 4])
+            p += 4
+            blk += raw[p: p + cb] if cb == ne else dec.decompress(raw[p: p + cb], decompressed_size=ne).to_pybytes()
+            p += cb
+        n_el = bsize // typesize
+        if flags & 0x4:  # bit shuffle: row (byte k, bit i) holds that bit of every element, 8 elements per byte, LSB first;
+            n8 = n_el - n_el % 8  # elements beyond a multiple of 8 (and a ragged tail) are stored as they are
+            rows = np.frombuffer(bytes(blk[: n8 * typesize]), np.uint8).reshape(typesize * 8, n8 // 8)
+            bits = np.unpackbits(rows, axis=1, bitorder="little")  # [byte*8 + bit, element]
+            body = np.packbits(bits.reshape(typesize, 8, n8).transpose(2, 0, 1), axis=2, bitorder="little").reshape(-1)
+            blk = body.tobytes() + bytes(blk[n8 * typesize:])
+        elif flags & 0x1 and typesize > 1:
+            body = np.frombuffer(bytes(blk[: n_el * typesize]), np.uint8).reshape(typesize, n_el).T.tobytes()
+            blk = body + bytes(blk[n_el * typesize:])
+        out += blk
+    return bytes(out)
 
 
 def read_array(path: str) -> np.ndarray:

@@ -58,3 +58,17 @@ def test_decoder_rejects_damaged_and_foreign_frames():
     assert rc != 0 or bytes(out.raw) != good
     with pytest.raises(Exception):
         zarr_io.read_array(os.path.join(FIX, "sst_gridded.zarr", "nothing_here"))
+
+
+def test_zstd_bitshuffle_coordinate_arrays():
+    """The lat / lon arrays of the reference's gridded SST store ({"cname": "zstd", "shuffle": 2}) decode to its regular
+    0.25-degree axes, and the whole store opens as a Dataset."""
+    pytest.importorskip("pyarrow")
+    lat = zarr_io.read_array(os.path.join(FIX, "sst_gridded.zarr", "lat"))
+    lon = zarr_io.read_array(os.path.join(FIX, "sst_gridded.zarr", "lon"))
+    assert lat.dtype == np.float32 and lat.shape == (20,) and lon.shape == (40,)
+    assert np.array_equal(lat, np.float32(35.125) + np.float32(0.25) * np.arange(20, dtype=np.float32))
+    assert np.array_equal(lon, np.float32(-39.875) + np.float32(0.25) * np.arange(40, dtype=np.float32))
+    ds = zarr_io.read_dataset(os.path.join(FIX, "sst_gridded.zarr"))
+    assert ds.to.dims == ("time", "lat", "lon") and ds.to.shape == (14611, 20, 40)
+    assert np.array_equal(ds.to.coords["lat"].values, lat) and str(ds.time.values[0])[:10] == "1982-01-01"
