@@ -729,13 +729,14 @@ def preprocess_data(
     tlead = (field.tdim, time_out)
     ds = Dataset()
     ds["dat_anomaly"] = field.labelled(out["dat_anomaly"], tlead)
-    ds["mask"] = field.labelled(out["mask"].astype(bool), None)
-    ds["extreme_events"] = field.labelled(out["extreme_events"].astype(bool), tlead)
+    as_bool = lambda a: a.view(np.bool_) if a.dtype == np.uint8 else a.astype(bool)  # noqa: E731  (kernels write 0 / 1)
+    ds["mask"] = field.labelled(as_bool(out["mask"]), None)
+    ds["extreme_events"] = field.labelled(as_bool(out["extreme_events"]), tlead)
     ds["thresholds"] = with_doy("thresholds", kinds["thresholds"])
     if want_stn:
         ds["dat_stn"] = field.labelled(out["dat_stn"], tlead)
         ds["STD"] = with_doy("STD", "doy_last")
-        ds["extreme_events_stn"] = field.labelled(out["extreme_events_stn"].astype(bool), tlead)
+        ds["extreme_events_stn"] = field.labelled(as_bool(out["extreme_events_stn"]), tlead)
         ds["thresholds_stn"] = with_doy("thresholds_stn", kinds["thresholds_stn"])
     if neighbours is not None:
         ds["neighbours"] = neighbours.astype(np.int32)
