@@ -5,6 +5,8 @@ optional damage to the field (NaN gaps in ocean cells, cells that start as NaN, 
 so that the kernel selection logic (fast / general anomaly kernel per chunk, tile shapes, speculative / exact threshold
 paths, short / long buckets) is exercised in combinations no hand-written case lists.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -48,7 +50,11 @@ def _case(seed):
                 seed=20240607 + seed, mutate=mutate if damage else None)
 
 
-@pytest.mark.parametrize("seed", list(range(36)))
+# MAREX_FUZZ_SEEDS="a:b" widens the sweep (one-off hunts; the default 36 cases keep the suite at a few minutes)
+_lo, _hi = (int(v) for v in os.environ.get("MAREX_FUZZ_SEEDS", "0:36").split(":"))
+
+
+@pytest.mark.parametrize("seed", list(range(_lo, _hi)))
 def test_random_configuration_matches_the_oracle(hot, seed):
     c = _case(seed)
     r = run_case(hot, c["start"], c["periods"], c["ny"], c["nx"], c["W"], c["S"], c["wd"], c["ws"], pct=c["pct"],
