@@ -52,7 +52,17 @@ struct marex_ctx {
     size_t detrend_scratch_bytes = 0;
     unsigned char* morph_scratch = nullptr;  // device, two bit-packed padded images of the morphology passes
     size_t morph_scratch_bytes = 0;
+    int n_cu = 0;  // compute units of the device (queried on first use)
 };
+
+static inline int device_cus(marex_ctx* ctx) {
+    if (ctx->n_cu <= 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n <= 0) n = 256;
+        ctx->n_cu = n;
+    }
+    return ctx->n_cu;
+}
 
 static inline int fail(marex_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];

@@ -238,14 +238,18 @@ k_thresholds(const unsigned short* __restrict__ bins, long T_out, long C, int ny
 #define TB_BATCH 16
 #endif
 
-template <int P, int TC, int NT>
+template <int P, int TC, int NT, int TR_ = NT / TC>
 __global__ void __launch_bounds__(NT, NT == 256 ? 4 : 1)
 k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, int nx, int row0, int row1, int tiles_x,
            int Dd, int shift, int env_exact, int ablate, const int* __restrict__ doy_start,
            const float* __restrict__ first_anom, const float* __restrict__ centres, int nb, double q, int wd,
            float lower_bound, float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats,
            unsigned char* __restrict__ gscratch, int coarse_pd) {
-    constexpr int TR = NT / TC;
+    // TR x TC tile cells on NT threads; a tile whose cell count is not a multiple of 64 (34 x 30 = 1020) leaves the last
+    // lanes of the last wave without a cell: they own a private, unused column and take part in the barriers only
+    constexpr int TR = TR_;
+    constexpr int NCELL = TR * TC;
+    static_assert(NCELL <= NT && NT - NCELL < 64, "tile does not match the thread count");
     constexpr int OR = TR - 2 * P, OC = TC - 2 * P;
     // lane-major level columns: TB_LS dwords (= 68 uint16 levels) per lane.  The stride 34 keeps 8-byte
     // alignment and makes 8-byte accesses of 32 consecutive lanes hit 64 distinct banks.
@@ -261,8 +265,10 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
     // lane -> tile cell: rows are rotated by P so that the output rows P .. TR-P-1 fill the FIRST waves completely and
     // the halo rows share the last one(s), which then skip the per-output phase (a 16x16 tile with P = 2: three waves
     // at 48/64 output lanes + one idle, instead of 24+48+48+24 over four)
+    const bool spare = NCELL < NT && t >= NCELL;
     const int tc = t % TC;
     const int tr = (TR > 1) ? (t / TC + P) % TR : 0;
+    const int ci = spare ? t : tr * TC + tc;  // column / total slot of this lane
     const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
     const int jt0 = row0 + ty * OR, it0 = tx * OC;
     const int j = (ny > 0) ? jt0 - P + tr : 0;
@@ -272,13 +278,13 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
     if (ny > 0) {
         int gi = icol % nx;
         if (gi < 0) gi += nx;
-        cell_valid = (j >= 0 && j < ny);
+        cell_valid = (j >= 0 && j < ny) && !spare;
         cell = (long)j * nx + gi;
     } else {
         cell_valid = icol < nx;
         cell = icol;
     }
-    const bool is_out = tr >= P && tr < TR - P && tc >= P && tc < TC - P && j < row1 && icol < nx;
+    const bool is_out = !spare && tr >= P && tr < TR - P && tc >= P && tc < TC - P && j < row1 && icol < nx;
     const int d_begin = (int)blockIdx.y * Dd;
     const int ndays = (NDOY - d_begin) < Dd ? (NDOY - d_begin) : Dd;
     const int pd = wd / 2;
@@ -293,7 +299,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         return;
     }
 
-    unsigned* mycol = &lev[(tr * TC + tc) * TB_LS];  // columns are indexed by tile cell: neighbour offsets stay linear
+    unsigned* mycol = &lev[ci * TB_LS];  // columns are indexed by tile cell: neighbour offsets stay linear
     uint2* mycol2 = reinterpret_cast<uint2*>(mycol);
     for (int r = 0; r < TB_LS / 2; ++r) mycol2[r] = make_uint2(0u, 0u);
     if (t == 0) {
@@ -564,7 +570,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
                     apply_bucket(pout, -1);
                 }
             }
-            if (!(ablate & 2)) tot_s[tr * TC + tc] = prefix(nlp);
+            if (!(ablate & 2)) tot_s[ci] = prefix(nlp);
             if (dd + 1 < nd_pass && !(ablate & 4)) {
                 pin = load_bucket((d + 1 + pd) % NDOY);
                 pout = load_bucket(((d - pd) % NDOY + NDOY) % NDOY);
@@ -729,11 +735,37 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
         const bool big = (ny > 0 && p > 0) && (tile_pref == 32 || tile_pref == 3216) && (row1 - row0) >= 16 && nx >= 16;
         const bool half = big && tile_pref == 3216;
         const int NT = big ? (half ? 512 : 1024) : 256;
-        const int TR = (ny > 0 && p > 0) ? (big ? (half ? 16 : 32) : 16) : 1, TC = NT / TR;
+        int TR = (ny > 0 && p > 0) ? (big ? (half ? 16 : 32) : 16) : 1, TC = NT / TR;
+        // a 34 x 30 tile (1020 cells) covers the same area per workgroup as 32 x 32: take whichever needs fewer tiles
+        // for the rows asked for (latitude bands of 90 rows: 3 x 56 tiles instead of 4 x 52, a fifth less work)
+        bool tall = false;
+        if (big && !half && p == 2 && env_int("MAREX_THR_TALL", 1)) {
+            auto ntiles = [&](int tr, int tc) {
+                return (long)((nx + tc - 2 * p - 1) / (tc - 2 * p)) * ((row1 - row0 + tr - 2 * p - 1) / (tr - 2 * p));
+            };
+            tall = ntiles(34, 30) < ntiles(32, 32) && (row1 - row0) >= 30;
+            if (tall) TR = 34, TC = 30;
+        }
         const int OR = TR - 2 * p, OC = TC - 2 * p;
-        int Dd = env_int("MAREX_THR_DD", big ? 48 : TB_DMAX);
-        if (Dd < 1 || Dd > (big ? 128 : TB_DMAX)) Dd = big ? 48 : TB_DMAX;
         const int tiles_x = (nx + OC - 1) / OC, tiles_y = (row1 - row0 + OR - 1) / OR;
+        int Dd = env_int("MAREX_THR_DD", 0);
+        if (Dd < 1 || Dd > (big ? 128 : TB_DMAX)) {
+            Dd = big ? 48 : TB_DMAX;
+            if (big && !half) {
+                // One 1024-thread tile per CU: the launch takes ceil(tiles * day-blocks / CUs) rounds of (Dd + wd - 1 + a few)
+                // bucket-days each (window build-up + placement pass).  Pick the day-block length with the least total
+                // -- e.g. 168 tiles on 256 CUs: 61 days (6 blocks, 3.94 rounds) beat 48 (8 blocks, 5.25 -> 6 rounds).
+                const long cus = device_cus(ctx), tiles = (long)tiles_x * tiles_y;
+                long best = -1;
+                // (not beyond 64 days: the speculative band is placed on the block's first day, and real thresholds drift
+                // with the season -- longer blocks would send more of them to the exact path)
+                for (int d = 40; d <= 64; ++d) {
+                    const long blocks = tiles * ((NDOY + d - 1) / d);
+                    const long cost = ((blocks + cus - 1) / cus) * (d + wd + 3);
+                    if (best < 0 || cost < best) best = cost, Dd = d;
+                }
+            }
+        }
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((NDOY + Dd - 1) / Dd));
         unsigned char* gscratch = nullptr;
         {  // per-(tile, day, lane) state bytes
@@ -757,6 +789,8 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
                 hipLaunchKernelGGL((k_thr_band<2, 32, 512>), grid, dim3(512), 0, ctx->stream, MAREX_BAND_ARGS);
             else if (big && p == 1)
                 hipLaunchKernelGGL((k_thr_band<1, 32, 1024>), grid, dim3(1024), 0, ctx->stream, MAREX_BAND_ARGS);
+            else if (big && p == 2 && tall)
+                hipLaunchKernelGGL((k_thr_band<2, 30, 1024, 34>), grid, dim3(1024), 0, ctx->stream, MAREX_BAND_ARGS);
             else if (big && p == 2)
                 hipLaunchKernelGGL((k_thr_band<2, 32, 1024>), grid, dim3(1024), 0, ctx->stream, MAREX_BAND_ARGS);
             else if (big)

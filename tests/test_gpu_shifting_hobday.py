@@ -171,3 +171,15 @@ def test_long_buckets_pick_the_big_tile(hot):
     """28 output years per dayofyear bucket on a 20x40 grid: the threshold entry point switches to 32x32 tiles."""
     r = run_case(hot, "1985-01-01", 32 * 365 + 8, 20, 40, 4, 21, 11, 5)
     check_all(*r)
+
+
+@pytest.mark.parametrize("ny,nx,env", [(30, 52, {}), (31, 27, {"MAREX_THR_EXACT_PATH": "1"}), (61, 53, {"MAREX_THR_DD": "9"}),
+                                       (30, 52, {"MAREX_THR_TALL": "0"})])
+def test_tall_tile_for_bands_it_tiles_better(hot, monkeypatch, ny, nx, env):
+    """34 x 30 tiles (1020 cells on 1024 threads, four spare lanes) replace 32 x 32 where they need fewer tiles -- e.g. 30
+    rows: one row of tiles instead of two; same bits as the oracle, also on the exact path and with short day blocks."""
+    monkeypatch.setenv("MAREX_THR_TILE", "32")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r = run_case(hot, "2001-01-01", 8 * 365 + 2, ny, nx, 3, 21, 11, 5)
+    check_all(*r)
