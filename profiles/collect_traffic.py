@@ -13,12 +13,13 @@ are known exactly), so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE matched kn
 import collections
 import csv
 import glob
+import os
 import json
 import sys
 
 
 def per_kernel(dirname, counter):
-    f = glob.glob(f"{dirname}/*/*_counter_collection.csv")[0]
+    f = sorted(glob.glob(f"{dirname}/*/*_counter_collection.csv"), key=os.path.getmtime)[-1]  # the latest run in that directory
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
