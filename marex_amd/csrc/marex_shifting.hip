@@ -357,18 +357,24 @@ __device__ __forceinline__ void stb_u16(rsrc_t r, unsigned voff, int soff, int v
 }
 
 #define SHIFT_INFO_WORDS 128  // [0..91] chunk handled by the fast kernel, [92] arange edges usable
+#define CLASSIFY_SPLIT 11      // threads per chunk in k_shift_classify (92 * 11 = 1012 <= 1024)
 
 __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, const float* __restrict__ edges, int nb,
                                  int want_bins, int enable, int* __restrict__ info) {
     __shared__ int s_edges_ok;
     const int t = threadIdx.x;
+    int eok = 1;
+    if (want_bins) {  // the table is an arange: every thread checks its share of the entries
+        const float first = edges[1], delta = edges[2] - edges[1];
+        for (int j = 1 + t; j <= nb; j += (int)blockDim.x)
+            eok = eok && __float_as_uint(edges[j]) == __float_as_uint(arange_edge(j, first, delta));
+    }
+    eok = __syncthreads_and(eok);
     if (t == 0) {
-        int ok = 1;
+        int ok = eok;
         if (want_bins) {
             const float first = edges[1], delta = edges[2] - edges[1], last = edges[nb];
-            ok = delta > 0.f && nb < 32768;
-            for (int j = 1; ok && j <= nb; ++j)
-                ok = __float_as_uint(edges[j]) == __float_as_uint(arange_edge(j, first, delta));
+            ok = ok && delta > 0.f && nb < 32768;
             // the fused guess (biased down by 1/128 bin) must land in the true bin or the one below: generous bound
             // on its rounding error (about 8x what the individual roundings add up to)
             const double m = fabs((double)first) > fabs((double)last) ? fabs((double)first) : fabs((double)last);
@@ -377,29 +383,36 @@ __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, 
         s_edges_ok = ok && enable;
         info[92] = s_edges_ok;
     }
+    __shared__ int s_ok[92];
+    if (t < 92) s_ok[t] = 1;
     __syncthreads();
-    if (t >= 92) return;
-    const int d0 = t * 4;
-    int ok = s_edges_ok;
     // every year: the first m (0..4) dayofyears of the chunk present on consecutive timesteps, the rest absent
-    // (leap day; dayofyears past 366 in the last chunk); output rows all or none, consecutive
-    for (int y = 0; ok && y < n_cal; ++y) {
-        int4 e[4];
-        for (int i = 0; i < 4; ++i)
-            e[i] = (d0 + i < NDOY) ? year_plan[(size_t)y * NDOY + d0 + i] : make_int4(-1, -1, -1, 0);
-        int m = 0;
-        while (m < 4 && e[m].x >= 0) ++m;
-        for (int i = m; i < 4; ++i) ok = ok && e[i].x < 0;
-        for (int i = 1; i < m; ++i) {
-            ok = ok && e[i].x == e[0].x + i;
-            if (e[0].y >= 0)
-                ok = ok && e[i].y == e[0].y + i && e[i].z >= 0;
-            else
-                ok = ok && e[i].y < 0;
+    // (leap day; dayofyears past 366 in the last chunk); output rows all or none, consecutive.
+    // CLASSIFY_SPLIT threads share the years of one chunk (the checks are chains of dependent global loads).
+    const int chunk = t / CLASSIFY_SPLIT, sub = t % CLASSIFY_SPLIT;
+    if (chunk < 92) {
+        const int d0 = chunk * 4;
+        int ok = 1;
+        for (int y = sub; y < n_cal; y += CLASSIFY_SPLIT) {
+            int4 e[4];
+            for (int i = 0; i < 4; ++i)
+                e[i] = (d0 + i < NDOY) ? year_plan[(size_t)y * NDOY + d0 + i] : make_int4(-1, -1, -1, 0);
+            int m = 0;
+            while (m < 4 && e[m].x >= 0) ++m;
+            for (int i = m; i < 4; ++i) ok = ok && e[i].x < 0;
+            for (int i = 1; i < m; ++i) {
+                ok = ok && e[i].x == e[0].x + i;
+                if (e[0].y >= 0)
+                    ok = ok && e[i].y == e[0].y + i && e[i].z >= 0;
+                else
+                    ok = ok && e[i].y < 0;
+            }
+            if (m > 0 && e[0].y >= 0) ok = ok && e[0].z >= 0;
         }
-        if (m > 0 && e[0].y >= 0) ok = ok && e[0].z >= 0;
+        if (!ok) atomicAnd(&s_ok[chunk], 0);
     }
-    info[t] = ok;
+    __syncthreads();
+    if (t < 92) info[t] = s_ok[t] && s_edges_ok;
 }
 
 template <int W>
@@ -717,7 +730,7 @@ extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64
     if (fast_cfg && !ctx->shift_info) HIP_TRY(ctx, hipMalloc((void**)&ctx->shift_info, SHIFT_INFO_WORDS * sizeof(int)));
     LaunchTimer lt(ctx, MAREX_K_SHIFTING);  // one timed region: classify + fast kernel + general kernel
     if (fast_cfg) {
-        hipLaunchKernelGGL(k_shift_classify, dim3(1), dim3(128), 0, ctx->stream, a.year_plan, n_cal_years, edges, nb,
+        hipLaunchKernelGGL(k_shift_classify, dim3(1), dim3(1024), 0, ctx->stream, a.year_plan, n_cal_years, edges, nb,
                            bins ? 1 : 0, 1, ctx->shift_info);
         a.skip = ctx->shift_info;
         switch (W) {
