@@ -155,14 +155,12 @@ def main():
                 x, dcal, W=W, S=wl["S"], bins=bt, q=wl["pct"] / 100.0, wd=wl["wd"], ws=wl["ws"],
                 ny=sh.ny_in, nx=nx, own_rows=(sh.own0 - sh.in0, sh.own1 - sh.in0), workspace=workspace,
             )
-            m = r["mask"][own].to(torch.int32)
-            inv = r["invalid_count"][own] * m
+            vs = hot.validation_summary(r["mask"], r["invalid_count"], (own.start, own.stop), workspace)  # a3 verdict
             st = r["stats_dev"]
-            local += torch.stack([
-                m.sum().to(torch.int64), inv.sum().to(torch.int64), (inv > 0).sum().to(torch.int64),
-                r["n_true"][0], st[2].to(torch.int64), st[3].to(torch.int64),
-            ])
-            mx = torch.maximum(mx, inv.max().to(torch.int64).reshape(1))
+            local[0:3] += vs[0:3]
+            local[3:4] += r["n_true"]
+            local[4:6] += st[2:4]
+            mx = torch.maximum(mx, vs[3:4])
         if world > 1:
             if backend != "nccl":  # gloo reduces host tensors
                 local, mx = local.cpu(), mx.cpu()

@@ -183,6 +183,13 @@ int marex_global_threshold_f32(marex_ctx* ctx, const float* anom, int64_t T_out,
                                const double* edges, const double* centres, int nb, double lower_bound,
                                double upper_bound, double* thr, marex_thr_stats* stats, double* minmax);
 
+/* Validation verdict (marEx/detect.py:205-279, `_validate_data_values`) from what the anomaly entry points leave per cell
+ * (`mask` = isfinite(x[0]), `invalid_count` = non-finite values over time), over cells c0 .. c1-1 (a shard's owned cells):
+ * out4 (device int64[4]) = {ocean cells, invalid values in ocean cells, ocean cells affected, worst cell's count} --
+ * the numbers of the reference's two error messages; shards combine them with one all-reduce (sum, sum, sum, max). */
+int marex_validation_summary(marex_ctx* ctx, const uint8_t* mask, const int32_t* invalid_count, int64_t c0, int64_t c1,
+                             int64_t* out4);
+
 /* extreme[t, c] = anom[t, c] >= thr[c] (comparison in float64, detect.py:2915) and the count of True */
 int marex_mask_ge_const_f32(marex_ctx* ctx, const float* anom, const double* thr, int64_t T_out, int64_t C,
                             uint8_t* extreme, unsigned long long* n_true);

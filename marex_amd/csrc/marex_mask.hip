@@ -198,6 +198,54 @@ __global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ in,
     }
 }
 
+// Verdict of the validation (detect.py:205-279) from the per-cell results of the anomaly kernels: over cells c0 .. c1-1
+// out[0] = ocean cells (mask != 0), out[1] = non-finite values in ocean cells, out[2] = ocean cells with any,
+// out[3] = the largest count in one ocean cell.
+__global__ void __launch_bounds__(256)
+k_validation_summary(const unsigned char* __restrict__ mask, const int* __restrict__ invalid, long c0, long c1,
+                     long long* __restrict__ out) {
+    long long n_ocean = 0, total = 0, cells = 0;
+    int worst = 0;
+    for (long c = c0 + (long)blockIdx.x * blockDim.x + threadIdx.x; c < c1; c += (long)gridDim.x * blockDim.x) {
+        const int m = mask[c] ? 1 : 0;
+        const int inv = m ? invalid[c] : 0;
+        n_ocean += m;
+        total += inv;
+        cells += inv > 0;
+        worst = inv > worst ? inv : worst;
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        n_ocean += __shfl_down(n_ocean, sft, 64);
+        total += __shfl_down(total, sft, 64);
+        cells += __shfl_down(cells, sft, 64);
+        const int w = __shfl_down(worst, sft, 64);
+        worst = w > worst ? w : worst;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_ocean) atomicAdd((unsigned long long*)&out[0], (unsigned long long)n_ocean);
+        if (total) atomicAdd((unsigned long long*)&out[1], (unsigned long long)total);
+        if (cells) atomicAdd((unsigned long long*)&out[2], (unsigned long long)cells);
+        if (worst) atomicMax(&out[3], (long long)worst);
+    }
+}
+
+extern "C" int marex_validation_summary(marex_ctx* ctx, const uint8_t* mask, const int32_t* invalid_count, int64_t c0,
+                                        int64_t c1, int64_t* out4) {
+    if (!ctx) return -1;
+    if (!mask || !invalid_count || !out4 || c0 < 0 || c1 < c0)
+        return fail(ctx, -1, "marex_validation_summary: null pointer or bad cell range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(out4, 0, 4 * sizeof(int64_t), ctx->stream));
+    if (c1 > c0) {
+        const long n = (long)(c1 - c0);
+        const int blocks = (int)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024);
+        hipLaunchKernelGGL(k_validation_summary, dim3(blocks), dim3(256), 0, ctx->stream, mask, invalid_count, (long)c0,
+                           (long)c1, reinterpret_cast<long long*>(out4));
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return 0;
+}
+
 extern "C" int marex_transpose_f32(marex_ctx* ctx, const float* in, int64_t rows, int64_t cols, float* out) {
     if (!ctx) return -1;
     if (!in || !out || rows <= 0 || cols <= 0) return fail(ctx, -1, "marex_transpose_f32: bad argument");

@@ -481,18 +481,11 @@ def _anomaly_core(eng, field: _Field, method_anomaly, window_year_baseline, smoo
     return {"anom": r["out"], "mask": r["mask"], "invalid": r["invalid_count"], "bins": r.get("bins"), "cal": cal, "dcal": dcal}
 
 
-def _validation_summary(a, own: Optional[slice] = None) -> Dict[str, int]:
-    import torch
-
-    own = slice(None) if own is None else own
-    m = a["mask"][own].to(torch.int32)
-    inv = a["invalid"][own] * m
-    return {
-        "n_ocean": int(m.sum().item()),
-        "invalid_total": int(inv.sum().item()),
-        "invalid_cells": int((inv > 0).sum().item()),
-        "max_invalid": int(inv.max().item()) if inv.numel() else 0,
-    }
+def _validation_summary(eng, a, own: Optional[slice] = None) -> Dict[str, int]:
+    n = a["mask"].shape[-1]
+    cells = (0, n) if own is None else own.indices(n)[:2]
+    v = eng.validation_summary(a["mask"], a["invalid"], cells).cpu().tolist()
+    return {"n_ocean": int(v[0]), "invalid_total": int(v[1]), "invalid_cells": int(v[2]), "max_invalid": int(v[3])}
 
 
 def _warn_threshold_range(stats: Dict[str, float], bt: binning.BinTable, max_anomaly: float) -> None:
@@ -665,7 +658,7 @@ def preprocess_data(
         a = _anomaly_core(eng, fb, method_anomaly, window_year_baseline, smooth_days_baseline, detrend_orders,
                           force_zero_mean, reference_period, need_bins)
         cal = a["cal"]
-        part = _validation_summary(a, sh.own_cell_slice())
+        part = _validation_summary(eng, a, sh.own_cell_slice())
         for k in ("n_ocean", "invalid_total", "invalid_cells"):
             total[k] += part[k]
         total["max_invalid"] = max(total["max_invalid"], part["max_invalid"])

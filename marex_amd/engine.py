@@ -194,7 +194,7 @@ class HotPath:
         thr = self._buf(wsp, "thr_doy_major", (N_DOY, Cn), torch.float32, self.device)
         stats = self._buf(wsp, "thr_stats", (4,), torch.int32, self.device)
         stats.zero_()
-        stats[0] = -1  # min_key = 0xFFFFFFFF
+        stats[0:1].fill_(-1)  # min_key = 0xFFFFFFFF (a fill kernel: `stats[0] = -1` would be a blocking host-to-device copy)
         centres = self.bin_tables(bins)[1]
         rc = self.lib.marex_hobday_thresholds_f32(
             self.ctx.handle, binsb.data_ptr(), T_out, Cn, int(ny), int(nx), dcal.doy_start.data_ptr(),
@@ -214,6 +214,20 @@ class HotPath:
             "n_too_low": int(s[2]),
             "n_too_high": int(s[3]),
         }
+
+    # ------------------------------------------------------------------ stage a3 verdict
+    def validation_summary(self, mask: torch.Tensor, invalid_count: torch.Tensor, cells: Optional[tuple] = None,
+                           wsp: Optional[dict] = None) -> torch.Tensor:
+        """Device int64 ``[n_ocean, invalid_total, invalid_cells, max_invalid]`` over the (owned) cells: the numbers of
+        ``_validate_data_values`` (detect.py:205-279) from the per-cell outputs of the anomaly kernels, one launch."""
+        self._bind_stream()
+        Cn = mask.shape[-1]
+        c0, c1 = cells if cells is not None else (0, Cn)
+        out = self._buf(wsp, "validation_summary", (4,), torch.int64, self.device)
+        rc = self.lib.marex_validation_summary(self.ctx.handle, mask.data_ptr(), invalid_count.data_ptr(), int(c0), int(c1),
+                                               out.data_ptr())
+        self.ctx.check(rc, "marex_validation_summary")
+        return out
 
     # ------------------------------------------------------------------ stage a9 compare
     def mask_ge_doy(

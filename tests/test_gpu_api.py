@@ -155,3 +155,19 @@ def test_public_subfunctions(hot):
     ext, thr = marex_amd.identify_extremes(an.dat_anomaly.isel(time=slice(int((~cal.kept).sum()), None)),
                                            method_extreme="hobday_extreme", threshold_percentile=95)
     assert ext.dtype == bool and thr.dims == ("lat", "lon", "dayofyear")
+
+
+def test_validation_summary_kernel(hot):
+    """marex_validation_summary == the NumPy form of _validate_data_values' counts (detect.py:224-279), any cell range."""
+    import torch
+
+    rng = np.random.default_rng(4)
+    for n in (1, 63, 64, 1000, 300001):
+        mask = (rng.random(n) < 0.7).astype(np.uint8)
+        inv = (rng.integers(0, 50, n) * (rng.random(n) < 0.1)).astype(np.int32)
+        md, iv = torch.from_numpy(mask).to(hot.device), torch.from_numpy(inv).to(hot.device)
+        for c0, c1 in ((0, n), (n // 3, n - n // 4), (n // 2, n // 2)):
+            got = hot.validation_summary(md, iv, (c0, c1)).cpu().tolist()
+            m, v = mask[c0:c1].astype(bool), inv[c0:c1]
+            exp = [int(m.sum()), int(v[m].sum()), int((v[m] > 0).sum()), int(v[m].max()) if m.any() else 0]
+            assert got == exp, (n, c0, c1)
