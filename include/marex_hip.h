@@ -134,6 +134,15 @@ int marex_mask_ge_doy_f32(marex_ctx* ctx, const float* anom, const float* thr_do
                           const int32_t* doy_start, const int32_t* doy_rows, int64_t T_out, int64_t C,
                           int64_t c0, int64_t c1, uint8_t* extreme, unsigned long long* n_true);
 
+/* The same mask, read from the bin matrix marex_shifting_baseline_f32 / marex_digitize_f32 produced for these anomalies
+ * (`bins`, `edges[0..nb]` as passed there): a sample whose bin lies above / below the bin of its threshold is decided
+ * without its value; only samples in the threshold's own bin or in the overflow bin nb are compared as numbers.  Same
+ * result bit for bit, 2 instead of 4 bytes read per sample.  Falls back to marex_mask_ge_doy_f32 for shapes its 4-cell
+ * kernel does not cover (C, c0, c1 not multiples of 4; unaligned pointers). */
+int marex_mask_ge_doy_bins_f32(marex_ctx* ctx, const float* anom, const uint16_t* bins, const float* edges, int nb,
+                               const float* thr_doy_major, const int32_t* doy_start, const int32_t* doy_rows, int64_t T_out,
+                               int64_t C, int64_t c0, int64_t c1, uint8_t* extreme, unsigned long long* n_true);
+
 /*
  * Fixed-baseline anomaly (detect.py:2299-2397): clim[d, c] = float32 nanmean of x over the timesteps with
  * dayofyear d (only those with use_row[t] != 0 when use_row is given: reference_period, 2334-2361),

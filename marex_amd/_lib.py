@@ -59,6 +59,7 @@ PROTOTYPES = {
     "marex_fill_holes_mesh_u8": (_i32, [_p, _p, _p, _p, _i64, _i64, _i32, _p]),
     "marex_label_mesh_i32": (_i32, [_p, _p, _p, _p, _i64, _i64, _p, _p]),
     "marex_validation_summary": (_i32, [_p, _p, _p, _i64, _i64, _p]),
+    "marex_mask_ge_doy_bins_f32": (_i32, [_p, _p, _p, _p, _i32, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "marex_blosc_decompress_h": (_i32, [_p, _i64, _p, _i64, _p]),
     "marex_blosc_compress_h": (_i32, [_p, _i64, _i32, _i32, _i64, _p, _i64, _p]),
     "marex_lz4_decode_streams": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _p, _p]),

@@ -149,7 +149,9 @@ __device__ __forceinline__ size_t bins_index(long r, long c, long T_out) {
 // increasing table.
 __device__ __forceinline__ int digitize_bin(float v, const float* e, int nb, float inv_width) {
     // straight-line: NaN / out-of-range inputs run through with a clamped guess and are fixed by selects at the end
-    int k = 1 + (int)((v - e[1]) * inv_width);
+    // the guess is clamped as a FLOAT: converting +-inf / huge values to int and adding 1 is signed-overflow UB, which
+    // the compiler turned into an unclamped index (NaN clamps to 0)
+    int k = 1 + (int)fminf(fmaxf((v - e[1]) * inv_width, 0.0f), (float)(nb - 2));
     k = k < 1 ? 1 : (k > nb - 1 ? nb - 1 : k);
     k += (v >= e[k + 1]) - (v < e[k]);  // the guess is off by at most one for equal-width tables
     k = k < 1 ? 1 : (k > nb - 1 ? nb - 1 : k);
@@ -168,7 +170,7 @@ __device__ __forceinline__ int digitize_bin(float v, const float* e, int nb, flo
 __device__ __forceinline__ float arange_edge(int j, float first, float delta) { return first + (float)(j - 1) * delta; }
 
 __device__ __forceinline__ int digitize_arange(float v, float first, float delta, float e_last, int nb, float inv_width) {
-    int k = 1 + (int)((v - first) * inv_width);
+    int k = 1 + (int)fminf(fmaxf((v - first) * inv_width, 0.0f), (float)(nb - 2));  // float clamp: see digitize_bin
     k = k < 1 ? 1 : (k > nb - 1 ? nb - 1 : k);
     k += (v >= arange_edge(k + 1, first, delta)) - (v < arange_edge(k, first, delta));
     k = k < 1 ? 1 : (k > nb - 1 ? nb - 1 : k);

@@ -73,6 +73,91 @@ k_mask_ge(const float* __restrict__ anom, const float* __restrict__ thr, const i
     }
 }
 
+// The same mask from the BIN matrix of the anomaly kernel (2 bytes per sample instead of 4): with k = bin(anom) and
+// kt = bin(thr) on the same increasing edge table, k > kt implies anom >= thr and k < kt implies anom < thr; only samples
+// in the threshold's own bin -- and those in the overflow bin nb, which also holds NaN -- need the anomaly itself
+// (about one sample in 500 for 0.01-wide bins).  A NaN threshold (land) never matches.  Bit-identical to k_mask_ge.
+__global__ void __launch_bounds__(256)
+k_mask_ge_bins(const float* __restrict__ anom, const unsigned short* __restrict__ bins, const float* __restrict__ edges,
+               int nb, const float* __restrict__ thr, const int* __restrict__ doy_start, const int* __restrict__ doy_rows,
+               long T_out, long C, long c0, long c1, unsigned char* __restrict__ out, unsigned long long* __restrict__ n_true) {
+    const int nchunk = (int)gridDim.y;
+    const int dA = (int)blockIdx.y * NDOY / nchunk, dB = ((int)blockIdx.y + 1) * NDOY / nchunk;
+    const long c = c0 + ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    unsigned cnt = 0;
+    if (c < c1) {
+        const float inv_width = (float)(nb - 1) / (edges[nb] - edges[1]);
+        const unsigned short* bcol = bins + bins_index(0, c, T_out);  // 4 cells of one 16-cell block; rows 16 elements apart
+        for (int d = dA; d < dB; ++d) {
+            const int r0 = doy_start[d], r1 = doy_start[d + 1];
+            if (r0 == r1) continue;
+            const float4 th = *reinterpret_cast<const float4*>(thr + (size_t)d * C + c);
+            const float tv[4] = {th.x, th.y, th.z, th.w};
+            int kt[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kt[i] = (tv[i] == tv[i]) ? digitize_bin(tv[i], edges, nb, inv_width) : 0x7fff;
+            auto one_row = [&](int r, uint2 b) {
+                const size_t off = (size_t)doy_rows[r] * C + c;
+                const int k[4] = {(int)(b.x & 0xFFFFu), (int)(b.x >> 16), (int)(b.y & 0xFFFFu), (int)(b.y >> 16)};
+                unsigned m[4];
+                bool need = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    m[i] = k[i] > kt[i];
+                    need = need || k[i] == kt[i] || (k[i] == nb && kt[i] != 0x7fff);
+                }
+                if (need) {  // rare: settle the four cells on the values themselves
+                    const float4 a = *reinterpret_cast<const float4*>(anom + off);
+                    m[0] = a.x >= tv[0];
+                    m[1] = a.y >= tv[1];
+                    m[2] = a.z >= tv[2];
+                    m[3] = a.w >= tv[3];
+                }
+                cnt += m[0] + m[1] + m[2] + m[3];
+                __builtin_nontemporal_store(m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24), reinterpret_cast<unsigned*>(out + off));
+            };
+            int r = r0;
+            for (; r + 4 <= r1; r += 4) {
+                uint2 b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const uint2*>(bcol + (size_t)(r + u) * 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) one_row(r + u, b[u]);
+            }
+            for (; r < r1; ++r) one_row(r, *reinterpret_cast<const uint2*>(bcol + (size_t)r * 16));
+        }
+    }
+    if (n_true) {
+        for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s, 64);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(n_true, (unsigned long long)cnt);
+    }
+}
+
+extern "C" int marex_mask_ge_doy_bins_f32(marex_ctx* ctx, const float* anom, const uint16_t* bins, const float* edges, int nb,
+                                          const float* thr_doy_major, const int32_t* doy_start, const int32_t* doy_rows,
+                                          int64_t T_out, int64_t C, int64_t c0, int64_t c1, uint8_t* extreme,
+                                          unsigned long long* n_true) {
+    if (!ctx) return -1;
+    if (!anom || !bins || !edges || !thr_doy_major || !doy_start || !doy_rows || !extreme || T_out <= 0 || C <= 0 || nb < 4)
+        return fail(ctx, -1, "marex_mask_ge_doy_bins_f32: null pointer or empty shape");
+    if (c0 < 0 || c1 > C || c0 >= c1) return fail(ctx, -1, "marex_mask_ge_doy_bins_f32: need 0 <= c0 < c1 <= C");
+    const bool vec = (C % 4 == 0) && (c0 % 4 == 0) && (c1 % 4 == 0) && (((uintptr_t)anom | (uintptr_t)thr_doy_major) % 16 == 0) &&
+                     ((uintptr_t)extreme % 4 == 0) && ((uintptr_t)bins % 8 == 0) && nb < 0x7fff;
+    if (!vec || env_int("MAREX_MASK_BINS", 1) == 0)  // shapes the 4-cell kernel does not cover: compare the values
+        return marex_mask_ge_doy_f32(ctx, anom, thr_doy_major, doy_start, doy_rows, T_out, C, c0, c1, extreme, n_true);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        LaunchTimer lt(ctx, MAREX_K_MASK);
+        const unsigned ncb4 = (unsigned)(((c1 - c0) / 4 + 255) / 256);
+        unsigned chunks = (4096 + ncb4 - 1) / ncb4;
+        chunks = chunks < MASK_DOY_CHUNKS ? MASK_DOY_CHUNKS : (chunks > 61 ? 61 : chunks);
+        hipLaunchKernelGGL(k_mask_ge_bins, dim3(ncb4, chunks), dim3(256), 0, ctx->stream, anom, bins, edges, nb, thr_doy_major,
+                           doy_start, doy_rows, (long)T_out, (long)C, (long)c0, (long)c1, extreme, n_true);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 extern "C" int marex_mask_ge_doy_f32(marex_ctx* ctx, const float* anom, const float* thr_doy_major,
                                      const int32_t* doy_start, const int32_t* doy_rows, int64_t T_out, int64_t C,
                                      int64_t c0, int64_t c1, uint8_t* extreme, unsigned long long* n_true) {

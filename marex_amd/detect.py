@@ -537,7 +537,7 @@ def _extremes_core(eng, a, field, method_extreme, threshold_percentile, window_d
             a["bins"], a["anom"], dcal, bt, threshold_percentile / 100.0, int(window_days_hobday),
             int(ws_eff) if ws_eff else 1, field.ny, field.nx, rows=rows,
         )
-        m = eng.mask_ge_doy(a["anom"], t["thr_doy_major"], dcal)
+        m = eng.mask_ge_doy(a["anom"], t["thr_doy_major"], dcal, binned=(a["bins"], bt))
         thr = eng.transpose(t["thr_doy_major"])
         range_stats(eng.decode_thr_stats(t["stats_dev"]), bt)
         return m["extreme"], thr, "doy_last", m["n_true"]

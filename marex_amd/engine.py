@@ -232,20 +232,30 @@ class HotPath:
     # ------------------------------------------------------------------ stage a9 compare
     def mask_ge_doy(
         self, anom: torch.Tensor, thr_doy_major: torch.Tensor, dcal: DeviceCalendar, cells: Optional[tuple] = None,
-        wsp: Optional[dict] = None,
+        wsp: Optional[dict] = None, binned: Optional[tuple] = None,
     ) -> Dict[str, torch.Tensor]:
-        """``cells=(c0, c1)`` restricts compare / write / count to the owned cells of a shard."""
+        """``cells=(c0, c1)`` restricts compare / write / count to the owned cells of a shard.  ``binned=(bin matrix,
+        BinTable)`` of these anomalies lets the kernel decide most samples from their 2-byte bin (same result)."""
         self._bind_stream()
         T_out, Cn = anom.shape
         c0, c1 = cells if cells is not None else (0, Cn)
         ext = self._buf(wsp, "extreme", (T_out, Cn), torch.uint8, self.device)
         n_true = self._buf(wsp, "n_true", (1,), torch.int64, self.device)
         n_true.zero_()
-        rc = self.lib.marex_mask_ge_doy_f32(
-            self.ctx.handle, anom.data_ptr(), thr_doy_major.data_ptr(), dcal.doy_start.data_ptr(),
-            dcal.doy_rows.data_ptr(), T_out, Cn, int(c0), int(c1), ext.data_ptr(), n_true.data_ptr(),
-        )
-        self.ctx.check(rc, "marex_mask_ge_doy_f32")
+        if binned is not None and binned[0] is not None:
+            edges = self.bin_tables(binned[1])[0]
+            rc = self.lib.marex_mask_ge_doy_bins_f32(
+                self.ctx.handle, anom.data_ptr(), binned[0].data_ptr(), edges.data_ptr(), int(binned[1].nb),
+                thr_doy_major.data_ptr(), dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), T_out, Cn, int(c0), int(c1),
+                ext.data_ptr(), n_true.data_ptr(),
+            )
+            self.ctx.check(rc, "marex_mask_ge_doy_bins_f32")
+        else:
+            rc = self.lib.marex_mask_ge_doy_f32(
+                self.ctx.handle, anom.data_ptr(), thr_doy_major.data_ptr(), dcal.doy_start.data_ptr(),
+                dcal.doy_rows.data_ptr(), T_out, Cn, int(c0), int(c1), ext.data_ptr(), n_true.data_ptr(),
+            )
+            self.ctx.check(rc, "marex_mask_ge_doy_f32")
         return {"extreme": ext, "n_true": n_true}
 
     def transpose(self, a: torch.Tensor, wsp: Optional[dict] = None, name: str = "transposed") -> torch.Tensor:
@@ -281,7 +291,7 @@ class HotPath:
         a = self.shifting_baseline(x, dcal, W, S, bins, wsp=workspace)
         cells = None if own_rows is None else (own_rows[0] * nx, own_rows[1] * nx)
         t = self.hobday_thresholds(a["bins"], a["out"], dcal, bins, q, wd, ws, ny, nx, rows=own_rows, wsp=workspace)
-        m = self.mask_ge_doy(a["out"], t["thr_doy_major"], dcal, cells=cells, wsp=workspace)
+        m = self.mask_ge_doy(a["out"], t["thr_doy_major"], dcal, cells=cells, wsp=workspace, binned=(a["bins"], bins))
         res = {
             "dat_anomaly": a["out"],
             "mask": a["mask"],

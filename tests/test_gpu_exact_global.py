@@ -117,3 +117,48 @@ def test_global_exact_with_ties_infinities_and_tiny_series(hot):
             exp = orc.global_threshold_exact(x, pct)
             got = hot.global_threshold(torch.from_numpy(x).to(hot.device), pct, "exact", None)["thr_f64"].cpu().numpy()
             assert np.array_equal(got, exp, equal_nan=True), (T, pct)
+
+
+@pytest.mark.parametrize("precision,max_anomaly", [(0.01, 5.0), (0.05, 2.0)])
+def test_mask_from_bins_equals_the_value_compare(hot, monkeypatch, precision, max_anomaly):
+    """marex_mask_ge_doy_bins_f32 decides most samples from their bin; thresholds and anomalies placed exactly on bin edges,
+    in the overflow bin, at +-inf and NaN must come out as `anom >= thr` does (detect.py:2003-2004)."""
+    import torch
+
+    rng = np.random.default_rng(12)
+    tm = calendar.daily_time_axis("2001-01-01", 3 * 365 + 1)
+    cal = calendar.build_calendar(tm)
+    dcal = hot.upload_calendar(cal)
+    bt = binning.hobday_bins(precision, max_anomaly)
+    T, C = len(tm), 4 * 300
+    e = bt.edges[1:]
+    anom = rng.normal(0, 1.5, (T, C)).astype(np.float32)
+    pick = rng.random((T, C))
+    anom[pick < 0.10] = rng.choice(e, int((pick < 0.10).sum()))               # exactly on an edge
+    anom[(pick > 0.10) & (pick < 0.12)] = np.nan
+    anom[(pick > 0.12) & (pick < 0.13)] = np.inf
+    anom[(pick > 0.13) & (pick < 0.14)] = -np.inf
+    anom[(pick > 0.14) & (pick < 0.16)] = np.float32(max_anomaly * 3)         # overflow bin
+    anom[(pick > 0.16) & (pick < 0.18)] = np.nextafter(rng.choice(e, int(((pick > 0.16) & (pick < 0.18)).sum())), np.float32(-np.inf))
+    thr = rng.normal(1.0, 1.0, (366, C)).astype(np.float32)
+    tp_ = rng.random((366, C))
+    thr[tp_ < 0.2] = rng.choice(e, int((tp_ < 0.2).sum()))
+    thr[(tp_ > 0.2) & (tp_ < 0.3)] = np.nan
+    thr[(tp_ > 0.3) & (tp_ < 0.32)] = np.inf
+    thr[(tp_ > 0.32) & (tp_ < 0.34)] = -np.inf
+    thr[(tp_ > 0.34) & (tp_ < 0.37)] = np.float32(max_anomaly * 2)
+    thr[(tp_ > 0.37) & (tp_ < 0.40)] = np.float32(-1.0)                       # below the first finite edge
+    ad, td = torch.from_numpy(anom).to(hot.device), torch.from_numpy(thr).to(hot.device)
+    bd = hot.digitize(ad, dcal, bt)
+    with np.errstate(invalid="ignore"):
+        exp = anom >= thr[cal.doy - 1]
+    for cells in (None, (4, C - 8)):
+        got = hot.mask_ge_doy(ad, td, dcal, cells=cells, binned=(bd, bt))
+        hot.sync()
+        c0, c1 = cells or (0, C)
+        assert np.array_equal(got["extreme"].cpu().numpy().astype(bool)[:, c0:c1], exp[:, c0:c1])
+        assert int(got["n_true"].item()) == int(exp[:, c0:c1].sum())
+    monkeypatch.setenv("MAREX_MASK_BINS", "0")  # the plain kernel behind the same entry point
+    got = hot.mask_ge_doy(ad, td, dcal, binned=(bd, bt))
+    hot.sync()
+    assert np.array_equal(got["extreme"].cpu().numpy().astype(bool), exp)
