@@ -77,54 +77,74 @@ k_mask_ge(const float* __restrict__ anom, const float* __restrict__ thr, const i
 // kt = bin(thr) on the same increasing edge table, k > kt implies anom >= thr and k < kt implies anom < thr; only samples
 // in the threshold's own bin -- and those in the overflow bin nb, which also holds NaN -- need the anomaly itself
 // (about one sample in 500 for 0.01-wide bins).  A NaN threshold (land) never matches.  Bit-identical to k_mask_ge.
+template <int VEC>  // cells per thread: 4 or 8 (8-/16-byte bin loads, 4-/8-byte mask stores)
 __global__ void __launch_bounds__(256)
 k_mask_ge_bins(const float* __restrict__ anom, const unsigned short* __restrict__ bins, const float* __restrict__ edges,
                int nb, const float* __restrict__ thr, const int* __restrict__ doy_start, const int* __restrict__ doy_rows,
                long T_out, long C, long c0, long c1, unsigned char* __restrict__ out, unsigned long long* __restrict__ n_true) {
+    constexpr int NW = VEC / 2;  // dwords of bins per row
+    typedef unsigned bw_t __attribute__((ext_vector_type(NW)));
     const int nchunk = (int)gridDim.y;
     const int dA = (int)blockIdx.y * NDOY / nchunk, dB = ((int)blockIdx.y + 1) * NDOY / nchunk;
-    const long c = c0 + ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long c = c0 + ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
     unsigned cnt = 0;
     if (c < c1) {
         const float inv_width = (float)(nb - 1) / (edges[nb] - edges[1]);
-        const unsigned short* bcol = bins + bins_index(0, c, T_out);  // 4 cells of one 16-cell block; rows 16 elements apart
+        const unsigned short* bcol = bins + bins_index(0, c, T_out);  // VEC cells of one 16-cell block; rows 16 elements apart
         for (int d = dA; d < dB; ++d) {
             const int r0 = doy_start[d], r1 = doy_start[d + 1];
             if (r0 == r1) continue;
-            const float4 th = *reinterpret_cast<const float4*>(thr + (size_t)d * C + c);
-            const float tv[4] = {th.x, th.y, th.z, th.w};
-            int kt[4];
+            float tv[VEC];
+            int kt[VEC];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) kt[i] = (tv[i] == tv[i]) ? digitize_bin(tv[i], edges, nb, inv_width) : 0x7fff;
-            auto one_row = [&](int r, uint2 b) {
+            for (int q = 0; q < VEC / 4; ++q) {
+                const float4 th = *reinterpret_cast<const float4*>(thr + (size_t)d * C + c + 4 * q);
+                tv[4 * q] = th.x, tv[4 * q + 1] = th.y, tv[4 * q + 2] = th.z, tv[4 * q + 3] = th.w;
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) kt[i] = (tv[i] == tv[i]) ? digitize_bin(tv[i], edges, nb, inv_width) : 0x7fff;
+            auto one_row = [&](int r, bw_t b) {
                 const size_t off = (size_t)doy_rows[r] * C + c;
-                const int k[4] = {(int)(b.x & 0xFFFFu), (int)(b.x >> 16), (int)(b.y & 0xFFFFu), (int)(b.y >> 16)};
-                unsigned m[4];
+                unsigned m[VEC];
                 bool need = false;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    m[i] = k[i] > kt[i];
-                    need = need || k[i] == kt[i] || (k[i] == nb && kt[i] != 0x7fff);
+                for (int i = 0; i < VEC; ++i) {
+                    const int k = (int)((b[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu);
+                    m[i] = k > kt[i];
+                    need = need || k == kt[i] || (k == nb && kt[i] != 0x7fff);
                 }
-                if (need) {  // rare: settle the four cells on the values themselves
-                    const float4 a = *reinterpret_cast<const float4*>(anom + off);
-                    m[0] = a.x >= tv[0];
-                    m[1] = a.y >= tv[1];
-                    m[2] = a.z >= tv[2];
-                    m[3] = a.w >= tv[3];
+                if (need) {  // rare: settle the cells on the values themselves
+#pragma unroll
+                    for (int q = 0; q < VEC / 4; ++q) {
+                        const float4 a = *reinterpret_cast<const float4*>(anom + off + 4 * q);
+                        m[4 * q] = a.x >= tv[4 * q];
+                        m[4 * q + 1] = a.y >= tv[4 * q + 1];
+                        m[4 * q + 2] = a.z >= tv[4 * q + 2];
+                        m[4 * q + 3] = a.w >= tv[4 * q + 3];
+                    }
                 }
-                cnt += m[0] + m[1] + m[2] + m[3];
-                __builtin_nontemporal_store(m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24), reinterpret_cast<unsigned*>(out + off));
+                typedef unsigned mw_t __attribute__((ext_vector_type(VEC / 4)));
+                mw_t w;
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) {
+                    w[q] = m[4 * q] | (m[4 * q + 1] << 8) | (m[4 * q + 2] << 16) | (m[4 * q + 3] << 24);
+                    cnt += m[4 * q] + m[4 * q + 1] + m[4 * q + 2] + m[4 * q + 3];
+                }
+                if constexpr (VEC == 4)
+                    __builtin_nontemporal_store(w[0], reinterpret_cast<unsigned*>(out + off));
+                else
+                    __builtin_nontemporal_store(w, reinterpret_cast<mw_t*>(out + off));
             };
+            auto load_row = [&](int r) { return *reinterpret_cast<const bw_t*>(bcol + (size_t)r * 16); };
             int r = r0;
             for (; r + 4 <= r1; r += 4) {
-                uint2 b[4];
+                bw_t b[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const uint2*>(bcol + (size_t)(r + u) * 16);
+                for (int u = 0; u < 4; ++u) b[u] = load_row(r + u);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) one_row(r + u, b[u]);
             }
-            for (; r < r1; ++r) one_row(r, *reinterpret_cast<const uint2*>(bcol + (size_t)r * 16));
+            for (; r < r1; ++r) one_row(r, load_row(r));
         }
     }
     if (n_true) {
@@ -148,11 +168,18 @@ extern "C" int marex_mask_ge_doy_bins_f32(marex_ctx* ctx, const float* anom, con
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     {
         LaunchTimer lt(ctx, MAREX_K_MASK);
-        const unsigned ncb4 = (unsigned)(((c1 - c0) / 4 + 255) / 256);
-        unsigned chunks = (4096 + ncb4 - 1) / ncb4;
+        const bool wide = (C % 8 == 0) && (c0 % 8 == 0) && (c1 % 8 == 0) && ((uintptr_t)bins % 16 == 0) &&
+                          ((uintptr_t)extreme % 8 == 0) && env_int("MAREX_MASK_VEC", 8) == 8;
+        const int vecw = wide ? 8 : 4;
+        const unsigned ncb = (unsigned)(((c1 - c0) / vecw + 255) / 256);
+        unsigned chunks = (4096 + ncb - 1) / ncb;
         chunks = chunks < MASK_DOY_CHUNKS ? MASK_DOY_CHUNKS : (chunks > 61 ? 61 : chunks);
-        hipLaunchKernelGGL(k_mask_ge_bins, dim3(ncb4, chunks), dim3(256), 0, ctx->stream, anom, bins, edges, nb, thr_doy_major,
-                           doy_start, doy_rows, (long)T_out, (long)C, (long)c0, (long)c1, extreme, n_true);
+        if (wide)
+            hipLaunchKernelGGL(k_mask_ge_bins<8>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, anom, bins, edges, nb,
+                               thr_doy_major, doy_start, doy_rows, (long)T_out, (long)C, (long)c0, (long)c1, extreme, n_true);
+        else
+            hipLaunchKernelGGL(k_mask_ge_bins<4>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, anom, bins, edges, nb,
+                               thr_doy_major, doy_start, doy_rows, (long)T_out, (long)C, (long)c0, (long)c1, extreme, n_true);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
