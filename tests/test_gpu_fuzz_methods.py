@@ -61,6 +61,7 @@ def test_random_method_pair_matches_the_oracle(hot, monkeypatch, seed):
     if mp == "approximate":
         kw.update(precision=prec, max_anomaly=maxa)
     monkeypatch.setenv("MAREX_BLOCKS", str(int(rng.choice([1, 1, 2, 3]))))
+    monkeypatch.setenv("MAREX_MASK_BINS", "1" if seed % 2 else "-1")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         ds = marex_amd.preprocess_data(da, **kw, **extra)

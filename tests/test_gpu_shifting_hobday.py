@@ -118,6 +118,7 @@ def test_threshold_kernel_variants(hot, monkeypatch):
         {"MAREX_THR_DD": "1"}, {"MAREX_THR_DD": "5"}, {"MAREX_THR_DD": "32"},
         {"MAREX_THR_EXACT_PATH": "1"}, {"MAREX_THR_TILE": "32"}, {"MAREX_THR_TILE": "32", "MAREX_THR_EXACT_PATH": "1"},
         {"MAREX_THR_TILE": "3216"}, {"MAREX_THR_TILE": "32", "MAREX_THR_DD": "7", "MAREX_THR_COARSE_PD": "5"},
+        {"MAREX_MASK_BINS": "1"}, {"MAREX_MASK_BINS": "1", "MAREX_MASK_VEC": "4"}, {"MAREX_MASK_BINS": "0"},
         {"MAREX_THR_ALGO": "1"}, {"MAREX_THR_ALGO": "1", "MAREX_THR_U32": "1"},
         {"MAREX_THR_ALGO": "1", "MAREX_THR_NW": "5"}, {"MAREX_THR_ALGO": "1", "MAREX_THR_NW": "64", "MAREX_THR_U32": "1"},
     )
