@@ -25,7 +25,7 @@ def step():
     d = hot.detrend(x, model, pmodel, True, None, count_invalid=True, wsp=ws)
     r = hot.fixed_baseline(d["out"], dcal, None, bt, count_invalid=False, wsp=ws)
     t = hot.hobday_thresholds(r["bins"], r["out"], dcal, bt, 0.90, 11, 5, ny, nx, rows=(2, 92), wsp=ws)
-    m = hot.mask_ge_doy(r["out"], t["thr_doy_major"], dcal, wsp=ws)
+    m = hot.mask_ge_doy(r["out"], t["thr_doy_major"], dcal, cells=(2 * nx, 92 * nx), wsp=ws, binned=(r["bins"], bt))
     return m
 
 
