@@ -108,3 +108,36 @@ def test_automatic_plan_is_one_block_when_the_field_fits(hot, monkeypatch):
     assert len(shards) > 1 and shards[0].in0 == 0 and shards[-1].in1 == 13
     assert all(s.in0 == max(0, s.own0 - 2) and s.in1 == min(13, s.own1 + 2) for s in shards)
     assert [s.own0 for s in shards[1:]] == [s.own1 for s in shards[:-1]]
+
+
+def test_pinned_pipe_round_trips_strided_arrays(hot):
+    """marex_amd.transfer.PinnedPipe: chunked, multi-threaded staging in both directions, strided host views, several
+    dtypes, more chunks than staging buffers, a row larger than a buffer."""
+    import torch
+
+    from marex_amd.transfer import PinnedPipe
+
+    pipe = PinnedPipe(hot.device, chunk_bytes=1 << 20, nbuf=3, threads=4)
+    rng = np.random.default_rng(8)
+    big = rng.normal(size=(700, 5000)).astype(np.float32)
+    for view in (big, big[:, 100:4100], big[5:, ::1][:, 7:8], big[:0], big[:, :0]):
+        dev = pipe.upload(view, np.float32)
+        assert tuple(dev.shape) == view.shape and np.array_equal(dev.cpu().numpy(), view)
+        back = np.full((view.shape[0], view.shape[1] + 3), -1, dtype=np.float32)
+        pipe.download(dev, back[:, 1:-2])
+        assert np.array_equal(back[:, 1:-2], view) and (back[:, 0] == -1).all() and (back[:, -2:] == -1).all()
+    f64 = rng.normal(size=(300, 1000))
+    assert np.array_equal(pipe.upload(f64, np.float32).cpu().numpy(), f64.astype(np.float32))  # cast on the way in
+    u8 = (rng.random((3000, 2048)) < 0.3).astype(np.uint8)
+    out = np.zeros_like(u8)
+    pipe.download(torch.from_numpy(u8).to(hot.device)[:, 8:2000], out[:, 8:2000])  # strided device view
+    assert np.array_equal(out[:, 8:2000], u8[:, 8:2000]) and not out[:, :8].any()
+    v = torch.arange(100000, dtype=torch.float64, device=hot.device)
+    o1 = np.empty(100000)
+    pipe.download(v, o1)
+    assert np.array_equal(o1, np.arange(100000.0))
+    wide = rng.normal(size=(3, 400000)).astype(np.float32)  # one row > chunk_bytes
+    assert np.array_equal(pipe.upload(wide, np.float32).cpu().numpy(), wide)
+    o2 = np.empty_like(wide)
+    pipe.download(torch.from_numpy(wide).to(hot.device), o2)
+    assert np.array_equal(o2, wide)
