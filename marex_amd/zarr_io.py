@@ -356,8 +356,11 @@ def write_dataset(store: str, ds, chunks: Dict[str, int] | None = None, compress
     import shutil
 
     chunks = dict({"time": 25}, **(chunks or {}))
-    if os.path.isdir(store):
-        shutil.rmtree(store)  # mode="w"
+    if os.path.isdir(store):  # mode="w" replaces a store -- but only something that IS a Zarr store (or an empty directory)
+        entries = os.listdir(store)
+        if entries and not any(e in entries for e in (".zgroup", ".zarray", ".zmetadata")):
+            raise DataValidationError("refusing to overwrite a directory that is not a Zarr store", details=store)
+        shutil.rmtree(store)
     os.makedirs(store)
     meta = {".zgroup": {"zarr_format": 2}, ".zattrs": {k: _json_attr(v) for k, v in getattr(ds, "attrs", {}).items()}}
     json.dump(meta[".zgroup"], open(os.path.join(store, ".zgroup"), "w"))

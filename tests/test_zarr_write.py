@@ -200,3 +200,18 @@ def test_dataset_round_trip_unstructured(tmp_path):
     assert back.attrs["preprocessing_steps"] == ["a", "b"]
     assert json.load(open(os.path.join(store, "extreme_events", ".zarray")))["dtype"] == "|b1"
     assert json.load(open(os.path.join(store, "dat_anomaly", ".zarray")))["chunks"] == [25, Cn]
+
+
+def test_to_zarr_refuses_to_replace_a_directory_that_is_no_store(tmp_path):
+    from marex_amd.exceptions import DataValidationError
+
+    d = tmp_path / "precious"
+    d.mkdir()
+    (d / "notes.txt").write_text("keep me")
+    ds = _MiniDataset({"a": _MiniDataArray(np.zeros((2, 3), np.float32), ("time", "x"))})
+    with pytest.raises(DataValidationError, match="not a Zarr store"):
+        ds.to_zarr(str(d), mode="w")
+    assert (d / "notes.txt").read_text() == "keep me"
+    ds.to_zarr(str(tmp_path / "fresh.zarr"))
+    ds.to_zarr(str(tmp_path / "fresh.zarr"), mode="w")  # an existing store is replaced
+    assert zarr_io.read_array(str(tmp_path / "fresh.zarr" / "a")).shape == (2, 3)
