@@ -749,7 +749,7 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
         const int OR = TR - 2 * p, OC = TC - 2 * p;
         const int tiles_x = (nx + OC - 1) / OC, tiles_y = (row1 - row0 + OR - 1) / OR;
         int Dd = env_int("MAREX_THR_DD", 0);
-        if (Dd < 1 || Dd > (big ? 128 : TB_DMAX)) {
+        if (Dd < 1 || Dd > 128) {
             Dd = big ? 48 : TB_DMAX;
             if (big && !half) {
                 // One 1024-thread tile per CU: the launch takes ceil(tiles * day-blocks / CUs) rounds of (Dd + wd - 1 + a few)
