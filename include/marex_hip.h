@@ -10,8 +10,10 @@
  *
  * Conventions
  *  - every function returns 0 on success, <0 on error; marex_last_error(ctx) gives the text.
- *  - no exceptions / longjmp cross the ABI; the library allocates nothing but the opaque context.
- *  - ALL data pointers are DEVICE pointers owned by the caller (small tables included).
+ *  - no exceptions / longjmp cross the ABI; the library owns only the opaque context and the device scratch buffers
+ *    inside it (freed by marex_destroy); every data buffer belongs to the caller.
+ *  - ALL data pointers are DEVICE pointers (small tables included), except in the entry points suffixed "_h" (the chunk
+ *    codec of the Zarr stores), which take HOST pointers.
  *  - work is enqueued on the context's HIP stream (marex_set_stream); marex_sync waits for it.
  *  - field layout is the reference's C-order (time, cells): element (t, c) at [t*C + c].
  *  - one context per (device, host thread).
