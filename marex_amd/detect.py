@@ -201,7 +201,13 @@ def _pipe(eng):
     if getattr(eng, "_pipe", None) is None:
         from .transfer import PinnedPipe
 
-        eng._pipe = PinnedPipe(eng.device)
+        import os
+
+        # 16 host threads / 128 MiB chunks measured best on the MI355X box (161 GB of results in 4.7 s; first-touch page
+        # faults of the destination arrays are part of what the threads share)
+        threads = int(os.environ.get("MAREX_PIPE_THREADS", str(min(16, os.cpu_count() or 4))))
+        eng._pipe = PinnedPipe(eng.device, chunk_bytes=int(os.environ.get("MAREX_PIPE_CHUNK_MB", "128")) << 20,
+                               nbuf=int(os.environ.get("MAREX_PIPE_NBUF", "4")), threads=threads)
     return eng._pipe
 
 
