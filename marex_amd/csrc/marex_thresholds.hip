@@ -653,16 +653,39 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
     // swings by 0.5 K over the year: 11.5 instead of 8.4 ms per 100-yr band with 61-day blocks)
     const int cpd = (coarse_pd >= 0 && coarse_pd < pd) ? coarse_pd : pd;
     sweep(0, 1, 0, cpd);
-    if (ndays > 1 && two_ended) sweep(0, 1, 0, cpd, ndays - 1);
-    int gmin = s_gmin, gmax = s_gmax;
+    const int gmin0 = s_gmin, gmax0 = s_gmax;
+    int gmin1 = gmin0, gmax1 = gmax0;
+    if (ndays > 1 && two_ended) {
+        __syncthreads();
+        if (t == 0) {
+            s_gmin = 255;
+            s_gmax = -1;
+        }
+        __syncthreads();
+        sweep(0, 1, 0, cpd, ndays - 1);
+        gmin1 = s_gmin;
+        gmax1 = s_gmax;
+    }
     __syncthreads();
+    const int nband = gpp < ngroups ? gpp : ngroups;
+    auto clamp_base = [&](int b) { return b < 0 ? 0 : (b + gpp > ngroups ? (ngroups - gpp > 0 ? ngroups - gpp : 0) : b); };
+    const bool seen0 = gmax0 >= 0, seen1 = gmax1 >= 0;
+    int gmin = seen0 && seen1 ? (gmin0 < gmin1 ? gmin0 : gmin1) : (seen0 ? gmin0 : gmin1);
+    int gmax = gmax0 > gmax1 ? gmax0 : gmax1;
     if (!env_exact && gmax >= 0 && gmax - gmin + 1 <= gpp) {
-        // speculative band of gpp groups placed around what the two ends need (room for drift on both sides)
+        // one speculative band of gpp groups around what the two ends need (room for drift on both sides)
         const int spare = gpp - (gmax - gmin + 1);
-        g_base = gmin - (spare + 1) / 2;
-        if (g_base < 0) g_base = 0;
-        if (g_base + gpp > ngroups) g_base = ngroups - gpp > 0 ? ngroups - gpp : 0;
-        sweep(1, ndays, gpp < ngroups ? gpp : ngroups, pd);
+        g_base = clamp_base(gmin - (spare + 1) / 2);
+        sweep(1, ndays, nband, pd);
+    } else if (!env_exact && seen0 && seen1 && ndays >= 8 && gmax0 - gmin0 + 1 <= gpp && gmax1 - gmin1 + 1 <= gpp) {
+        // the drift across the block is wider than one band: one band per half, each anchored on its own end with all
+        // its spare groups on the side the thresholds come from / go to
+        const bool up = gmin1 + gmax1 > gmin0 + gmax0;
+        const int nd_a = ndays / 2;
+        g_base = clamp_base(up ? gmin0 : gmax0 - gpp + 1);
+        sweep(1, nd_a, nband, pd);
+        g_base = clamp_base(up ? gmax1 - gpp + 1 : gmin1);
+        sweep(1, ndays - nd_a, nband, pd, nd_a);
     } else if (t == 0) {
         s_unres = 1;
     }
