@@ -49,7 +49,7 @@ class HotPath:
         self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
         self.ctx = _lib.Context(self.device.index)
         self.lib = self.ctx.lib
-        self._tables: Dict[int, tuple] = {}
+        self._tables: Dict[tuple, tuple] = {}
         self._bind_stream()
 
     @staticmethod
@@ -101,11 +101,14 @@ class HotPath:
         return binsb.permute(1, 0, 2).reshape(T_out, nblk * 16)[:, :C]
 
     def bin_tables(self, bins: BinTable):
-        """(edges, centres) of a bin table on the device, uploaded once per table object."""
-        key = id(bins)
+        """(edges, centres) of a bin table on the device, uploaded once per table CONTENT (callers build a fresh BinTable
+        per call; a handful of distinct tables at most stay resident)."""
+        key = (float(bins.precision), float(bins.max_anomaly), int(bins.nb), bins.edges.tobytes())
         if key not in self._tables:
-            self._tables[key] = (self._dev(bins.edges, np.float32), self._dev(bins.centres, np.float32), bins)
-        return self._tables[key][:2]
+            if len(self._tables) >= 8:
+                self._tables.pop(next(iter(self._tables)))
+            self._tables[key] = (self._dev(bins.edges, np.float32), self._dev(bins.centres, np.float32))
+        return self._tables[key]
 
     # ------------------------------------------------------------------ synthetic field
     def synth_field(self, tab, cell_base: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:

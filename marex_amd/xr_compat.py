@@ -195,8 +195,12 @@ class _MiniDataset:
         """``Dataset.to_zarr`` as the reference's batch script calls it (examples/batch jobs/run_detect.py:83)."""
         from .zarr_io import write_dataset
 
+        import os
+
         if mode not in ("w", "w-"):
-            raise ValueError("the stand-in Dataset writes whole stores only (mode='w')")
+            raise ValueError("the stand-in Dataset writes whole stores only (mode='w' or 'w-')")
+        if mode == "w-" and os.path.exists(str(store)):  # xarray: "w-" means create, fail if the store exists
+            raise FileExistsError(f"path {str(store)!r} contains a store (mode='w-' never overwrites)")
         write_dataset(str(store), self, chunks)
 
     def __repr__(self):  # pragma: no cover

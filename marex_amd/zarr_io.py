@@ -119,6 +119,59 @@ def decode_cf_time(values: np.ndarray, attrs: Dict) -> np.ndarray:
     return (t0 + values.astype(np.int64).astype(f"timedelta64[{step}]")).astype("datetime64[D]" if step == "D" else "datetime64[s]")
 
 
+def plan_blosc_frame(raw: bytes, typesize: int, expected_nbytes: int, where: str = "<frame>"):
+    """Parse and VALIDATE the header of one Blosc-1 / LZ4 frame for the device decoder (the host decoder
+    ``marex_blosc_decompress_h`` makes the same checks for itself).  The device kernels bound their reads only by the
+    stream sizes uploaded with the chunk, so every offset and size is checked against the frame here, before anything is
+    sent to the GPU: a truncated or corrupt chunk raises ``DataValidationError`` instead of faulting on the device.
+
+    Returns ``(shuffled, streams, blocks)``: ``streams`` = ``(offset of the compressed bytes in the frame, compressed size,
+    destination offset in the chunk's byte planes, raw size)``, ``blocks`` = ``(plane offset, first element relative to the
+    chunk, elements, bytes)``."""
+    import struct
+
+    def bad(msg):
+        return DataValidationError("malformed Blosc frame", details=f"{where}: {msg}")
+
+    if len(raw) < 16:
+        raise bad(f"{len(raw)} bytes, shorter than the 16-byte header")
+    _, _, flags, ts, nbytes, blocksize, cbytes = struct.unpack("<BBBBIII", raw[:16])
+    if flags & 0x2 or flags & 0x4 or (flags >> 5) != 1 or ts != typesize:
+        raise DependencyError("device read: LZ4 Blosc frames with byte shuffle only", details=f"{where}: flags {flags:#x}, typesize {ts}")
+    if cbytes != len(raw):
+        raise bad(f"header says {cbytes} compressed bytes, the file holds {len(raw)}")
+    if nbytes != expected_nbytes:
+        raise bad(f"header says {nbytes} decoded bytes, the chunk shape needs {expected_nbytes}")
+    if blocksize <= 0 or nbytes <= 0:
+        raise bad(f"blocksize {blocksize}, nbytes {nbytes}")
+    nblocks = (nbytes + blocksize - 1) // blocksize
+    table_end = 16 + 4 * nblocks
+    if table_end > len(raw):
+        raise bad(f"block table of {nblocks} entries does not fit {len(raw)} bytes")
+    bstarts = struct.unpack(f"<{nblocks}i", raw[16:table_end])
+    shuffled = bool(flags & 0x1) and ts > 1
+    streams, blocks = [], []
+    for j in range(nblocks):
+        bsize = nbytes - j * blocksize if j == nblocks - 1 else blocksize
+        leftover = bsize != blocksize
+        nsplits = ts if (not (flags & 0x10) and not leftover and ts <= 16 and blocksize // ts >= 128 and bsize % ts == 0) else 1
+        neblock = bsize // nsplits
+        p = bstarts[j]
+        if p < table_end or p + 4 > len(raw):
+            raise bad(f"block {j} starts at {p}, outside [{table_end}, {len(raw) - 4}]")
+        for s in range(nsplits):
+            if p + 4 > len(raw):
+                raise bad(f"block {j} stream {s}: size field at {p} past the end of the frame")
+            (cb,) = struct.unpack("<i", raw[p:p + 4])
+            p += 4
+            if cb < 0 or cb > neblock or p + cb > len(raw):
+                raise bad(f"block {j} stream {s}: {cb} compressed bytes at {p} (raw size {neblock}, frame {len(raw)})")
+            streams.append((p, cb, j * blocksize + s * neblock, neblock))
+            p += cb
+        blocks.append((j * blocksize, j * (blocksize // ts), bsize // ts, bsize))
+    return shuffled, streams, blocks
+
+
 def read_array_to_device(path: str, eng, lead: int | None = None):
     """Read a Zarr v2 array whose chunks span every dimension but the first (``chunks = (ct, *shape[1:])``, the layout of
     the reference's time-chunked stores) straight into HBM: the COMPRESSED chunk bytes are uploaded, the LZ4 streams are
@@ -144,52 +197,53 @@ def read_array_to_device(path: str, eng, lead: int | None = None):
     s_src, s_cs, s_dst, s_raw = [], [], [], []
     b_off, b_e0, b_ne, b_valid = [], [], [], []
     planes_size, shuffled = 0, None
+    chunk_bytes = int(np.prod(chunks)) * ts
+    missing = []  # (first element, one-past-last element) of chunks without a file: left at the fill value, as read_array does
     for ci in range((T + chunks[0] - 1) // chunks[0]):
         f = os.path.join(path, sep.join([str(ci)] + ["0"] * (len(shape) - 1)))
+        elem_first = ci * chunks[0] * per_step
+        elem_valid_end = T * per_step
+        if not os.path.exists(f):
+            missing.append((elem_first, min(elem_first + chunks[0] * per_step, elem_valid_end)))
+            continue
         raw = open(f, "rb").read()
-        _, _, flags, typesize, nbytes, blocksize, cbytes = struct.unpack("<BBBBIII", raw[:16])
-        if flags & 0x2 or flags & 0x4 or (flags >> 5) != 1 or typesize != ts or cbytes != len(raw):
-            raise DependencyError("device read: LZ4 Blosc frames with byte shuffle only", details=f"{f}: flags {flags:#x}, typesize {typesize}")
-        sh = bool(flags & 0x1) and ts > 1
+        sh, streams, blocks = plan_blosc_frame(raw, ts, chunk_bytes, f)
         if shuffled is None:
             shuffled = sh
         elif shuffled != sh:
             raise DependencyError("device read: mixed shuffle settings")
-        nblocks = (nbytes + blocksize - 1) // blocksize
-        bstarts = struct.unpack(f"<{nblocks}i", raw[16:16 + 4 * nblocks])
-        elem_first = ci * chunks[0] * per_step
-        elem_valid_end = T * per_step
-        for j in range(nblocks):
-            bsize = nbytes - j * blocksize if j == nblocks - 1 else blocksize
-            leftover = bsize != blocksize
-            nsplits = ts if (not (flags & 0x10) and not leftover and ts <= 16 and blocksize // ts >= 128 and bsize % ts == 0) else 1
-            neblock = bsize // nsplits
-            p = bstarts[j]
-            for s in range(nsplits):
-                (cb,) = struct.unpack("<i", raw[p:p + 4])
-                p += 4
-                s_src.append(pos + p)
-                s_cs.append(cb)
-                s_dst.append(planes_size + s * neblock)
-                s_raw.append(neblock)
-                p += cb
-            ne = bsize // ts
-            e0 = elem_first + j * (blocksize // ts)
-            b_off.append(planes_size)
+        for (p, cb, dst, neblock) in streams:
+            s_src.append(pos + p)
+            s_cs.append(cb)
+            s_dst.append(planes_size + dst)
+            s_raw.append(neblock)
+        for (off, e_rel, ne, bsize) in blocks:
+            e0 = elem_first + e_rel
+            b_off.append(planes_size + off)
             b_e0.append(e0)
             b_ne.append(ne)
             b_valid.append(int(max(0, min(ne, elem_valid_end - e0))))
-            planes_size += bsize
+        planes_size += chunk_bytes
         blobs.append(raw)
         pos += len(raw)
     dev = eng.device
+    planes = torch.empty(max(planes_size, 1), dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    out = torch.empty(T * per_step * ts, dtype=torch.uint8, device=dev)
+    tdt = {"float32": torch.float32, "float64": torch.float64, "int32": torch.int32, "int64": torch.int64, "int8": torch.int8,
+           "uint8": torch.uint8, "int16": torch.int16, "bool": torch.bool}[dtype.name]
+    if missing:
+        fv = meta.get("fill_value")
+        fv = float("nan") if fv in ("NaN", None) and dtype.kind == "f" else (0 if fv is None else fv)
+        typed = out.view(tdt)
+        for e0, e1 in missing:
+            typed[e0:e1] = fv
+    if not s_src:
+        return out.view(tdt).reshape((T,) + shape[1:])
     comp_d = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).to(dev)
     tab = lambda a, dt: torch.from_numpy(np.asarray(a, dtype=dt)).to(dev)  # noqa: E731
     t_src, t_cs, t_dst, t_raw = tab(s_src, np.int64), tab(s_cs, np.int32), tab(s_dst, np.int64), tab(s_raw, np.int32)
     t_off, t_e0, t_ne, t_valid = tab(b_off, np.int64), tab(b_e0, np.int64), tab(b_ne, np.int32), tab(b_valid, np.int32)
-    planes = torch.empty(planes_size, dtype=torch.uint8, device=dev)
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
-    out = torch.empty(T * per_step * ts, dtype=torch.uint8, device=dev)
     eng._bind_stream()
     rc = eng.lib.marex_lz4_decode_streams(eng.ctx.handle, comp_d.data_ptr(), t_src.data_ptr(), t_cs.data_ptr(), t_dst.data_ptr(),
                                           t_raw.data_ptr(), len(s_src), int(max(s_raw)), planes.data_ptr(), status.data_ptr())
@@ -200,8 +254,6 @@ def read_array_to_device(path: str, eng, lead: int | None = None):
     eng.sync()
     if int(status.item()) != 0:
         raise DataValidationError("malformed LZ4 stream in a chunk", details=f"{int(status.item())} streams failed")
-    tdt = {"float32": torch.float32, "float64": torch.float64, "int32": torch.int32, "int64": torch.int64, "int8": torch.int8,
-           "uint8": torch.uint8, "int16": torch.int16, "bool": torch.bool}[dtype.name]
     return out.view(tdt).reshape((T,) + shape[1:])
 
 

@@ -145,12 +145,12 @@ def make_fixture_stats():
 
     R = "/root/reference/tests/data"
     arrays = {
-        "sst_to_first5490": z.read_array(R + "/sst_gridded.zarr/to")[:5490],
-        "sst_time_first5490": z.read_array(R + "/sst_gridded.zarr/time")[:5490],
+        "sst_to": z.read_array(R + "/sst_gridded.zarr/to"),
+        "sst_time": z.read_array(R + "/sst_gridded.zarr/time"),
         "extreme_events": z.read_array(R + "/extremes_gridded.zarr/extreme_events"),
         "mask": z.read_array(R + "/extremes_gridded.zarr/mask"),
-        "sst_unstructured_to_first5479": z.read_array(R + "/sst_unstructured.zarr/to")[:5479],
-        "sst_unstructured_time_first5479": z.read_array(R + "/sst_unstructured.zarr/time")[:5479],
+        "sst_unstructured_to": z.read_array(R + "/sst_unstructured.zarr/to"),
+        "sst_unstructured_time": z.read_array(R + "/sst_unstructured.zarr/time"),
         "unstructured_extreme_events": z.read_array(R + "/extremes_unstructured.zarr/extreme_events"),
         "unstructured_mask": z.read_array(R + "/extremes_unstructured.zarr/mask"),
         "unstructured_neighbours": z.read_array(R + "/extremes_unstructured.zarr/neighbours"),

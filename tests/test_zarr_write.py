@@ -215,3 +215,17 @@ def test_to_zarr_refuses_to_replace_a_directory_that_is_no_store(tmp_path):
     ds.to_zarr(str(tmp_path / "fresh.zarr"))
     ds.to_zarr(str(tmp_path / "fresh.zarr"), mode="w")  # an existing store is replaced
     assert zarr_io.read_array(str(tmp_path / "fresh.zarr" / "a")).shape == (2, 3)
+
+
+def test_mode_w_minus_never_overwrites(tmp_path):
+    """xarray semantics: mode="w-" creates a store and fails if it exists; only mode="w" replaces one."""
+    from marex_amd.xr_compat import _MiniDataArray, _MiniDataset
+
+    ds = _MiniDataset({"v": _MiniDataArray(np.arange(6, dtype=np.float32).reshape(2, 3), dims=("a", "b"), coords={})}, attrs={})
+    store = str(tmp_path / "s.zarr")
+    ds.to_zarr(store, mode="w-")
+    first = open(os.path.join(store, "v", ".zarray")).read()
+    with pytest.raises(FileExistsError):
+        ds.to_zarr(store, mode="w-")
+    assert open(os.path.join(store, "v", ".zarray")).read() == first
+    ds.to_zarr(store, mode="w")  # replaces
