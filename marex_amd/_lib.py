@@ -60,6 +60,15 @@ PROTOTYPES = {
     "marex_label_mesh_i32": (_i32, [_p, _p, _p, _p, _i64, _i64, _p, _p]),
     "marex_validation_summary": (_i32, [_p, _p, _p, _i64, _i64, _p]),
     "marex_mask_ge_doy_bins_f32": (_i32, [_p, _p, _p, _p, _i32, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
+    "marex_set_option": (_i32, [_p, C.c_char_p, _i32]),
+    "marex_clear_option": (_i32, [_p, C.c_char_p]),
+    "marex_debug_counters": (_i32, [_p, _p, _i32]),
+    "marex_tail_extract_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _p, _i32, _i32, _p, _p]),
+    "marex_hobday_thresholds_tails_f32": (
+        _i32,
+        [_p, _p, _p, _i32, _p, _i64, _i64, _i32, _i32, _p, _p, _i32, _p, _p, _i32, _f64, _i32, _i32, _f32, _f32, _i32, _i32, _p, _p],
+    ),
+    "marex_mask_ge_doy_tails_f32": (_i32, [_p, _p, _p, _i32, _p, _p, _i32, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "marex_blosc_decompress_h": (_i32, [_p, _i64, _p, _i64, _p]),
     "marex_blosc_compress_h": (_i32, [_p, _i64, _i32, _i32, _i64, _p, _i64, _p]),
     "marex_lz4_decode_streams": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _p, _p]),
@@ -78,6 +87,7 @@ KERNEL_IDS = {
     "global": 8,
     "stdnorm": 9,
     "morph": 10,
+    "tails": 11,
 }
 
 _lib: Optional[C.CDLL] = None
@@ -145,6 +155,35 @@ class Context:
 
     def sync(self) -> None:
         self.check(self.lib.marex_sync(self.handle), "marex_sync")
+
+    def set_option(self, name: str, value: Optional[int]) -> None:
+        """Set (or, with ``None``, clear) a tuning / diagnostic option of this context (include/marex_hip.h)."""
+        if value is None:
+            self.check(self.lib.marex_clear_option(self.handle, name.encode()), "marex_clear_option")
+        else:
+            self.check(self.lib.marex_set_option(self.handle, name.encode(), int(value)), "marex_set_option")
+
+    def options(self, **opts):
+        """Context manager: ``with ctx.options(THR_DD=5, THR_TILE=16): ...`` -- the options are cleared afterwards."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            for k, v in opts.items():
+                self.set_option(k, v)
+            try:
+                yield self
+            finally:
+                for k in opts:
+                    self.set_option(k, None)
+
+        return _cm()
+
+    def debug_counters(self, reset: bool = True):
+        """Event counters of the tail kernels as a list of 8 ints (synchronises)."""
+        buf = (C.c_uint64 * 8)()
+        self.check(self.lib.marex_debug_counters(self.handle, buf, int(reset)), "marex_debug_counters")
+        return [int(v) for v in buf]
 
     def timing_enable(self, on: bool = True) -> None:
         self.check(self.lib.marex_timing_enable(self.handle, int(on)), "marex_timing_enable")

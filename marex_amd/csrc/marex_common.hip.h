@@ -8,6 +8,7 @@
 //   marex_mask.hip        anomaly >= threshold, transpose
 //   marex_anomalies.hip   fixed baseline, digitize, detrend, std_normalise
 //   marex_quantiles.hip   exact Hobday percentile, global thresholds
+//   marex_tails.hip       tail extraction, thresholds and mask from tails (the default approximate-Hobday path)
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC, one object per file, linked -shared (csrc/build.py).
 // -ffp-contract=off is part of the arithmetic contract (oracle/marex_oracle.py C1-C6): every float
@@ -22,6 +23,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -53,7 +55,32 @@ struct marex_ctx {
     unsigned char* morph_scratch = nullptr;  // device, two bit-packed padded images of the morphology passes
     size_t morph_scratch_bytes = 0;
     int n_cu = 0;  // compute units of the device (queried on first use)
+    std::map<std::string, int> opts;          // tuning / diagnostic options (marex_set_option; seeded from MAREX_* at creation)
+    unsigned long long* dbg_counters = nullptr;  // device, MAREX_DBG_COUNTERS event counters of the tail kernels
 };
+
+#define MAREX_DBG_COUNTERS 8
+
+// Option lookup: options are set through marex_set_option (or, once, from the environment variables MAREX_<NAME> that
+// exist when the context is created); nothing reads the environment at launch time.
+static inline int ctx_opt(marex_ctx* ctx, const char* name, int dflt) {
+    auto it = ctx->opts.find(name);
+    return it == ctx->opts.end() ? dflt : it->second;
+}
+
+#ifdef MAREX_ABLATION
+#define MAREX_ABLATE_OPT(ctx, name) ctx_opt(ctx, name, 0)
+#else
+#define MAREX_ABLATE_OPT(ctx, name) 0
+#endif
+
+static inline unsigned long long* ctx_debug_counters(marex_ctx* ctx) {
+    if (!ctx->dbg_counters) {
+        if (hipMalloc((void**)&ctx->dbg_counters, MAREX_DBG_COUNTERS * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        (void)hipMemsetAsync(ctx->dbg_counters, 0, MAREX_DBG_COUNTERS * sizeof(unsigned long long), ctx->stream);
+    }
+    return ctx->dbg_counters;
+}
 
 static inline int device_cus(marex_ctx* ctx) {
     if (ctx->n_cu <= 0) {
@@ -111,11 +138,6 @@ static inline void drain_timers(marex_ctx* ctx) {
         (void)hipEventDestroy(p.b);
     }
     ctx->pending.clear();
-}
-
-static inline int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -9,7 +9,45 @@ extern "C" int marex_create(int device, marex_ctx** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return -3;
     marex_ctx* c = new marex_ctx();
     c->device = device;
+    // options: MAREX_<NAME>=<int> present in the environment NOW seed the table (experiments, A/B runs); later changes
+    // go through marex_set_option
+    extern char** environ;
+    for (char** e = environ; e && *e; ++e) {
+        if (strncmp(*e, "MAREX_", 6) != 0) continue;
+        const char* eq = strchr(*e, '=');
+        if (!eq || eq == *e + 6) continue;
+        char* end = nullptr;
+        const long v = strtol(eq + 1, &end, 10);
+        if (end == eq + 1 || *end != '\0') continue;  // not an integer (paths, seed ranges ...)
+        c->opts[std::string(*e + 6, (size_t)(eq - (*e + 6)))] = (int)v;
+    }
     *out = c;
+    return 0;
+}
+
+extern "C" int marex_set_option(marex_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name || !*name) return -1;
+    ctx->opts[name] = value;
+    return 0;
+}
+
+extern "C" int marex_clear_option(marex_ctx* ctx, const char* name) {
+    if (!ctx) return -1;
+    if (!name)
+        ctx->opts.clear();
+    else
+        ctx->opts.erase(name);
+    return 0;
+}
+
+extern "C" int marex_debug_counters(marex_ctx* ctx, uint64_t* out, int reset) {
+    if (!ctx || !out) return -1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long* d = ctx_debug_counters(ctx);
+    if (!d) return fail(ctx, -2, "marex_debug_counters: allocation failed");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, d, MAREX_DBG_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(ctx, hipMemsetAsync(d, 0, MAREX_DBG_COUNTERS * sizeof(unsigned long long), ctx->stream));
     return 0;
 }
 
@@ -20,6 +58,7 @@ extern "C" int marex_destroy(marex_ctx* ctx) {
     if (ctx->thr_scratch) (void)hipFree(ctx->thr_scratch);
     if (ctx->detrend_scratch) (void)hipFree(ctx->detrend_scratch);
     if (ctx->morph_scratch) (void)hipFree(ctx->morph_scratch);
+    if (ctx->dbg_counters) (void)hipFree(ctx->dbg_counters);
     delete ctx;
     return 0;
 }

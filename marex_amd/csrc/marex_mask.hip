@@ -165,7 +165,7 @@ extern "C" int marex_mask_ge_doy_bins_f32(marex_ctx* ctx, const float* anom, con
                      ((uintptr_t)extreme % 4 == 0) && ((uintptr_t)bins % 8 == 0) && nb < 0x7fff;
     // Short dayofyear buckets (few years) make the per-bucket runs of the bin matrix shorter than a cache line or two: the
     // plain compare is faster there (10-yr field: 1.9 vs 2.1 ms); long ones win by a third (100-yr band: 4.2 -> 2.9 ms).
-    const int mode = env_int("MAREX_MASK_BINS", -1);  // -1 auto, 0 never, 1 whenever the shapes allow
+    const int mode = ctx_opt(ctx, "MASK_BINS", -1);  // -1 auto, 0 never, 1 whenever the shapes allow
     const bool worth = mode == 1 || (mode < 0 && T_out / NDOY >= 24);
     if (!vec || !worth)  // also: shapes the 4-cell kernel does not cover
         return marex_mask_ge_doy_f32(ctx, anom, thr_doy_major, doy_start, doy_rows, T_out, C, c0, c1, extreme, n_true);
@@ -173,7 +173,7 @@ extern "C" int marex_mask_ge_doy_bins_f32(marex_ctx* ctx, const float* anom, con
     {
         LaunchTimer lt(ctx, MAREX_K_MASK);
         const bool wide = (C % 8 == 0) && (c0 % 8 == 0) && (c1 % 8 == 0) && ((uintptr_t)bins % 16 == 0) &&
-                          ((uintptr_t)extreme % 8 == 0) && env_int("MAREX_MASK_VEC", 8) == 8;
+                          ((uintptr_t)extreme % 8 == 0) && ctx_opt(ctx, "MASK_VEC", 8) == 8;
         const int vecw = wide ? 8 : 4;
         const unsigned ncb = (unsigned)(((c1 - c0) / vecw + 255) / 256);
         unsigned chunks = (4096 + ncb - 1) / ncb;

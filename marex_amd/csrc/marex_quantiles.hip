@@ -510,7 +510,7 @@ extern "C" int marex_global_threshold_f32(marex_ctx* ctx, const float* anom, int
     if (!(q >= 0.0 && q <= 1.0)) return fail(ctx, -1, "marex_global_threshold_f32: q must be in [0, 1]");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     LaunchTimer lt(ctx, MAREX_K_GLOBAL);
-    const bool small_counts = T_out <= 65535 && env_int("MAREX_GLOBAL_V1", 0) == 0;  // uint16 counters suffice
+    const bool small_counts = T_out <= 65535 && ctx_opt(ctx, "GLOBAL_V1", 0) == 0;  // uint16 counters suffice
     if (exact && small_counts) {
         const size_t lds = 128 * G2_LANES * 4;  // 32 KiB
         hipLaunchKernelGGL(k_global_exact16, dim3((unsigned)((C + G2_LANES - 1) / G2_LANES)), dim3(G2_LANES), lds,

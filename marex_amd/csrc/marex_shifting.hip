@@ -19,6 +19,9 @@ k_shifting(const float* __restrict__ x, long T, long C, const int4* __restrict__
            unsigned short* __restrict__ bins, unsigned char* __restrict__ mask, int* __restrict__ invalid_count,
            int ncb, int nchunks, int ablate, const int* __restrict__ skip) {
     extern __shared__ float lds[];
+#ifndef MAREX_ABLATION
+    ablate = 0;  // the timing-only ablation bits (wrong results by design) exist only in -DMAREX_ABLATION builds
+#endif
     // W-year history of every (cell, dayofyear).  LDS ring [D][WCAP][256] (slots W..WCAP-1 hold +0.0, neutral in
     // the sum), or -- RREG -- a register shift line per dayofyear: rr[i][WCAP-W .. WCAP-1] = years y-W .. y-1,
     // the leading WCAP-W entries stay +0.0.  The register line frees the LDS, so occupancy is set by VGPRs only.
@@ -684,7 +687,7 @@ static int launch_shifting(marex_ctx* ctx, const ShiftArgs& a) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(xcd_grid(ncb, nchunks)), dim3(256), lds, ctx->stream, a.x, (long)a.T, (long)a.C,
                        a.year_plan, a.n_cal, a.W, a.S, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins,
-                       a.mask, a.invalid_count, ncb, nchunks, env_int("MAREX_SHIFT_ABLATE", 0), D == 4 ? a.skip : nullptr);
+                       a.mask, a.invalid_count, ncb, nchunks, MAREX_ABLATE_OPT(ctx, "SHIFT_ABLATE"), D == 4 ? a.skip : nullptr);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -721,12 +724,12 @@ extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64
                 edges, nb, T_out, out, bins, mask, invalid_count, nullptr};
     // 4 dayofyears per workgroup (6 row loads per output) while the padded W-year LDS ring leaves room for two
     // workgroups per CU, otherwise one dayofyear
-    const int forceD = env_int("MAREX_SHIFT_D", 0);
-    const int reg = env_int("MAREX_SHIFT_RING", 1);  // 1 (default): history in registers, 0: LDS ring
+    const int forceD = ctx_opt(ctx, "SHIFT_D", 0);
+    const int reg = ctx_opt(ctx, "SHIFT_RING", 1);  // 1 (default): history in registers, 0: LDS ring
     // regular chunks of the calendar go to k_shift_fast (S = 21, instantiated W, arange edge table)
     const bool fast_w = W == 3 || W == 4 || W == 5 || W == 6 || W == 7 || W == 10 || W == 13 || W == 15;
-    const bool fast_cfg = env_int("MAREX_SHIFT_FAST", 1) != 0 && S == 21 && fast_w && forceD == 0 && T >= 24 &&
-                          T_out < (1 << 24) && C < (1 << 24) && env_int("MAREX_SHIFT_ABLATE", 0) == 0;
+    const bool fast_cfg = ctx_opt(ctx, "SHIFT_FAST", 1) != 0 && S == 21 && fast_w && forceD == 0 && T >= 24 &&
+                          T_out < (1 << 24) && C < (1 << 24) && MAREX_ABLATE_OPT(ctx, "SHIFT_ABLATE") == 0;
     if (fast_cfg && !ctx->shift_info) HIP_TRY(ctx, hipMalloc((void**)&ctx->shift_info, SHIFT_INFO_WORDS * sizeof(int)));
     LaunchTimer lt(ctx, MAREX_K_SHIFTING);  // one timed region: classify + fast kernel + general kernel
     if (fast_cfg) {

@@ -251,6 +251,9 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
     constexpr int NCELL = TR * TC;
     static_assert(NCELL <= NT && NT - NCELL < 64, "tile does not match the thread count");
     constexpr int OR = TR - 2 * P, OC = TC - 2 * P;
+#ifndef MAREX_ABLATION
+    ablate = 0;  // timing-only ablation bits: -DMAREX_ABLATION builds only
+#endif
     // lane-major level columns: TB_LS dwords (= 68 uint16 levels) per lane.  The stride 34 keeps 8-byte
     // alignment and makes 8-byte accesses of 32 consecutive lanes hit 64 distinct banks.
     __shared__ unsigned lev[NT * TB_LS];
@@ -751,14 +754,14 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
     // ---- band algorithm (default) whenever its uint16 level counters and 64-bin bands suffice
     int shift = 0;
     while ((((nb - 1) >> shift) + 1) > 32) ++shift;  // at most 32 coarse groups
-    const int algo = env_int("MAREX_THR_ALGO", 0);   // 0 auto, 1 force sliding histograms
+    const int algo = ctx_opt(ctx, "THR_ALGO", 0);   // 0 auto, 1 force sliding histograms
     const int p = ws / 2;
     const bool band_ok = (1 << shift) <= 64 && p <= 3 && max_bucket > 0 && (int64_t)max_bucket * wd * ws * ws <= 65535;
     if (algo != 1 && band_ok) {
         // tile: 16x16 cells / 256 threads, or 32x32 / 1024 threads (less halo redundancy, more output lanes)
         // long dayofyear buckets (many years) make the kernel sample-streaming bound: the big tile re-streams
         // 1.31x instead of 1.78x halo cells per output cell (measured 17.4 vs 23.3 ms on an 85-year band)
-        const int tile_pref = env_int("MAREX_THR_TILE", max_bucket >= 24 ? 32 : 16);
+        const int tile_pref = ctx_opt(ctx, "THR_TILE", max_bucket >= 24 ? 32 : 16);
         // tile_pref 32: 32x32 cells / 1024 threads (one workgroup per CU); 3216: 32 wide x 16 tall / 512 threads (two
         // independent workgroups per CU); 16: 16x16 / 256 threads
         const bool big = (ny > 0 && p > 0) && (tile_pref == 32 || tile_pref == 3216) && (row1 - row0) >= 16 && nx >= 16;
@@ -768,7 +771,7 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
         // a 34 x 30 tile (1020 cells) covers the same area per workgroup as 32 x 32: take whichever needs fewer tiles
         // for the rows asked for (latitude bands of 90 rows: 3 x 56 tiles instead of 4 x 52, a fifth less work)
         bool tall = false;
-        if (big && !half && p == 2 && env_int("MAREX_THR_TALL", 1)) {
+        if (big && !half && p == 2 && ctx_opt(ctx, "THR_TALL", 1)) {
             auto ntiles = [&](int tr, int tc) {
                 return (long)((nx + tc - 2 * p - 1) / (tc - 2 * p)) * ((row1 - row0 + tr - 2 * p - 1) / (tr - 2 * p));
             };
@@ -777,7 +780,7 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
         }
         const int OR = TR - 2 * p, OC = TC - 2 * p;
         const int tiles_x = (nx + OC - 1) / OC, tiles_y = (row1 - row0 + OR - 1) / OR;
-        int Dd = env_int("MAREX_THR_DD", 0);
+        int Dd = ctx_opt(ctx, "THR_DD", 0);
         if (Dd < 1 || Dd > 128) {
             Dd = big ? 48 : TB_DMAX;
             if (big && !half) {
@@ -808,8 +811,8 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
             }
             gscratch = ctx->thr_scratch;
         }
-        const int coarse_pd = env_int("MAREX_THR_COARSE_PD", 1);
-#define MAREX_BAND_ARGS bins, (long)T_out, (long)C, ny, nx, row0, row1, tiles_x, Dd, shift, env_int("MAREX_THR_EXACT_PATH", 0), env_int("MAREX_THR_ABLATE", 0), doy_start, first_anom, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats, gscratch, coarse_pd, env_int("MAREX_THR_TWO_ENDS", 1)
+        const int coarse_pd = ctx_opt(ctx, "THR_COARSE_PD", 1);
+#define MAREX_BAND_ARGS bins, (long)T_out, (long)C, ny, nx, row0, row1, tiles_x, Dd, shift, ctx_opt(ctx, "THR_EXACT_PATH", 0), MAREX_ABLATE_OPT(ctx, "THR_ABLATE"), doy_start, first_anom, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats, gscratch, coarse_pd, ctx_opt(ctx, "THR_TWO_ENDS", 1)
         {
             LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
             if (TR == 1)
@@ -838,9 +841,9 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
 
     // ---- sliding pooled histograms (any nb / ws / bucket size)
     // uint16 counters are enough when even "all samples of the pooled window in one bin" fits
-    const bool pack = max_bucket > 0 && (int64_t)max_bucket * wd * ws * ws <= 65535 && !env_int("MAREX_THR_U32", 0);
+    const bool pack = max_bucket > 0 && (int64_t)max_bucket * wd * ws * ws <= 65535 && !ctx_opt(ctx, "THR_U32", 0);
     const int nbw = pack ? (nb + 1) / 2 : nb;
-    int NW = env_int("MAREX_THR_NW", 16);
+    int NW = ctx_opt(ctx, "THR_NW", 16);
     if (NW < 1 || NW > 64) NW = 16;
     const size_t budget = 80 * 1024;  // per workgroup of 4 waves: two workgroups per CU
     while (NW > 1 && 4 * (size_t)NW * (nbw + 3) * 4 > budget) NW >>= 1;

@@ -454,10 +454,12 @@ def _anomaly_core(eng, field: _Field, method_anomaly, window_year_baseline, smoo
                 details=f"no timestep is left after removing the first {window_year_baseline} years",
             )
         dcal = eng.upload_calendar(cal)
+        want_bins = want_bins(dcal) if callable(want_bins) else want_bins
         r = eng.shifting_baseline(x, dcal, int(window_year_baseline), int(smooth_days_baseline), want_bins)
         return {"anom": r["out"], "mask": r["mask"], "invalid": r["invalid_count"], "bins": r.get("bins"), "cal": cal, "dcal": dcal}
     cal = calendar.build_calendar(field.time)
     dcal = eng.upload_calendar(cal)
+    want_bins = want_bins(dcal) if callable(want_bins) else want_bins
     if method_anomaly == "fixed_baseline":
         _check_reference_period_values(reference_period, cal.year)
         r = eng.fixed_baseline(x, dcal, reference_period, want_bins, count_invalid=True)
@@ -539,14 +541,13 @@ def _extremes_core(eng, a, field, method_extreme, threshold_percentile, window_d
             thr_doy = eng.hobday_thresholds_exact(a["anom"], dcal, float(threshold_percentile), int(window_days_hobday))
             m = eng.mask_ge_doy(a["anom"], thr_doy, dcal)
             return m["extreme"], thr_doy, "doy_first", m["n_true"]
-        t = eng.hobday_thresholds(
-            a["bins"], a["anom"], dcal, bt, threshold_percentile / 100.0, int(window_days_hobday),
-            int(ws_eff) if ws_eff else 1, field.ny, field.nx, rows=rows,
+        t = eng.hobday_approx(
+            a["anom"], dcal, bt, threshold_percentile / 100.0, int(window_days_hobday),
+            int(ws_eff) if ws_eff else 1, field.ny, field.nx, rows=rows, binsb=a.get("bins"),
         )
-        m = eng.mask_ge_doy(a["anom"], t["thr_doy_major"], dcal, binned=(a["bins"], bt))
         thr = eng.transpose(t["thr_doy_major"])
         range_stats(eng.decode_thr_stats(t["stats_dev"]), bt)
-        return m["extreme"], thr, "doy_last", m["n_true"]
+        return t["extreme"], thr, "doy_last", t["n_true"]
     # global_extreme
     g = eng.global_threshold(a["anom"], float(threshold_percentile), method_percentile, bt)
     if method_percentile == "approximate":
@@ -658,11 +659,19 @@ def preprocess_data(
         else:
             dst[...] = view.cpu().numpy()
 
+    # the anomaly kernels emit the bin matrix only where the threshold stage will use it (engine.tails_plan: the
+    # tail kernels take most configurations and read the anomalies themselves)
+    bins_for = None
+    if need_bins is not None:
+        def bins_for(dcal):
+            k = eng.tails_plan(dcal, need_bins, threshold_percentile / 100.0, int(window_days_hobday), int(ws_eff) if ws_eff else 1)
+            return need_bins if k is None else None
+
     for sh in blocks:
         fb = field if single else field.block(sh)
         rows = None if single or not field.gridded else (sh.own0 - sh.in0, sh.own1 - sh.in0)
         a = _anomaly_core(eng, fb, method_anomaly, window_year_baseline, smooth_days_baseline, detrend_orders,
-                          force_zero_mean, reference_period, need_bins)
+                          force_zero_mean, reference_period, bins_for)
         cal = a["cal"]
         part = _validation_summary(eng, a, sh.own_cell_slice())
         for k in ("n_ocean", "invalid_total", "invalid_cells"):
@@ -685,8 +694,6 @@ def preprocess_data(
                 logger.info("Processing standardised anomalies for extreme identification")
             sn = eng.std_normalise(a["anom"], a["dcal"])
             a_stn = {"anom": sn["dat_stn"], "cal": cal, "dcal": a["dcal"], "bins": None}
-            if need_bins is not None:
-                a_stn["bins"] = eng.digitize(sn["dat_stn"], a["dcal"], bt, wsp={})
             ext_s, thr_s, kind_s, _ = _extremes_core(
                 eng, a_stn, fb, method_extreme, threshold_percentile, window_days_hobday, ws_eff, method_percentile, bt,
                 max_anomaly, wsp={}, rows=rows, defer=defer,
@@ -856,8 +863,6 @@ def identify_extremes(
     dcal = eng.upload_calendar(cal)
     anom = field.device_x(eng)
     a = {"anom": anom, "cal": cal, "dcal": dcal, "bins": None}
-    if method_extreme == "hobday_extreme" and method_percentile == "approximate":
-        a["bins"] = eng.digitize(anom, dcal, bt)
     ext, thr, kind, _ = _extremes_core(
         eng, a, field, method_extreme, threshold_percentile, window_days_hobday, ws_eff, method_percentile, bt, max_anomaly
     )

@@ -50,6 +50,9 @@ class HotPath:
         self.ctx = _lib.Context(self.device.index)
         self.lib = self.ctx.lib
         self._tables: Dict[tuple, tuple] = {}
+        #: None = choose per configuration (tails_plan); "tails" / "bins" force the representation of the dayofyear
+        #: histograms behind the approximate Hobday thresholds (same results either way; tests use it)
+        self.hobday_path: Optional[str] = None
         self._bind_stream()
 
     @staticmethod
@@ -218,6 +221,91 @@ class HotPath:
             "n_too_high": int(s[3]),
         }
 
+    # ------------------------------------------------------------------ stage a10/a11 on tails (default)
+    def tails_plan(self, dcal: DeviceCalendar, bins: BinTable, q: float, wd: int, ws: int) -> Optional[int]:
+        """Number of keys per (dayofyear, cell) tail (16 / 32) when the tail kernels take this configuration, else None
+        (bin-matrix kernels).  Results are identical on both paths; the rule only keeps the threshold kernel away from
+        tails that are too short for the quantile asked for (it would re-read most buckets from the anomalies)."""
+        if self.hobday_path == "bins":
+            return None
+        nd = int(np.diff(dcal.plan.doy_start).max())
+        if not (bins.nb <= 511 and 1 <= nd <= 128 and ws <= 7 and nd * wd * ws * ws <= 65535):
+            return None
+        K = 16 if nd <= 16 else 32
+        if self.hobday_path != "tails" and nd > K and nd * (1.0 - q) > K / 3.0:
+            return None
+        return K
+
+    def tail_extract(self, anom: torch.Tensor, dcal: DeviceCalendar, bins: BinTable, K: int, wsp: Optional[dict] = None):
+        """Sorted upper tails of every (dayofyear, cell) bucket of ``anom`` (include/marex_hip.h, TAILS)."""
+        self._bind_stream()
+        T_out, Cn = anom.shape
+        edges = self.bin_tables(bins)[0]
+        tails = self._buf(wsp, "tails", (N_DOY, K // 8, Cn, 8), torch.int16, self.device)
+        aux = self._buf(wsp, "tails_aux", (N_DOY, Cn), torch.int16, self.device)
+        rc = self.lib.marex_tail_extract_f32(
+            self.ctx.handle, anom.data_ptr(), T_out, Cn, dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(),
+            int(np.diff(dcal.plan.doy_start).max()), edges.data_ptr(), bins.nb, int(K), tails.data_ptr(), aux.data_ptr(),
+        )
+        self.ctx.check(rc, "marex_tail_extract_f32")
+        return {"tails": tails, "aux": aux, "K": int(K), "_keep": edges}
+
+    def hobday_thresholds_tails(self, tl: dict, anom: torch.Tensor, dcal: DeviceCalendar, bins: BinTable, q: float, wd: int,
+                                ws: int, ny: int, nx: int, rows: Optional[tuple] = None, wsp: Optional[dict] = None):
+        self._bind_stream()
+        T_out, Cn = anom.shape
+        row0, row1 = rows if rows is not None else (0, max(ny, 1))
+        thr = self._buf(wsp, "thr_doy_major", (N_DOY, Cn), torch.float32, self.device)
+        stats = self._buf(wsp, "thr_stats", (4,), torch.int32, self.device)
+        stats.zero_()
+        stats[0:1].fill_(-1)
+        edges, centres = self.bin_tables(bins)
+        rc = self.lib.marex_hobday_thresholds_tails_f32(
+            self.ctx.handle, tl["tails"].data_ptr(), tl["aux"].data_ptr(), int(tl["K"]), anom.data_ptr(), T_out, Cn, int(ny),
+            int(nx), dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), int(np.diff(dcal.plan.doy_start).max()),
+            edges.data_ptr(), centres.data_ptr(), bins.nb, float(q), int(wd), int(ws), float(bins.lower_bound),
+            float(bins.upper_bound), int(row0), int(row1), thr.data_ptr(), stats.data_ptr(),
+        )
+        self.ctx.check(rc, "marex_hobday_thresholds_tails_f32")
+        return {"thr_doy_major": thr, "stats_dev": stats, "_keep": (edges, centres)}
+
+    def mask_ge_doy_tails(self, tl: dict, anom: torch.Tensor, thr_doy_major: torch.Tensor, dcal: DeviceCalendar,
+                          bins: BinTable, cells: Optional[tuple] = None, wsp: Optional[dict] = None):
+        self._bind_stream()
+        T_out, Cn = anom.shape
+        c0, c1 = cells if cells is not None else (0, Cn)
+        ext = self._buf(wsp, "extreme", (T_out, Cn), torch.uint8, self.device)
+        n_true = self._buf(wsp, "n_true", (1,), torch.int64, self.device)
+        n_true.zero_()
+        edges = self.bin_tables(bins)[0]
+        rc = self.lib.marex_mask_ge_doy_tails_f32(
+            self.ctx.handle, tl["tails"].data_ptr(), tl["aux"].data_ptr(), int(tl["K"]), anom.data_ptr(), edges.data_ptr(),
+            bins.nb, thr_doy_major.data_ptr(), dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), T_out, Cn, int(c0), int(c1),
+            ext.data_ptr(), n_true.data_ptr(),
+        )
+        self.ctx.check(rc, "marex_mask_ge_doy_tails_f32")
+        return {"extreme": ext, "n_true": n_true}
+
+    def hobday_approx(self, anom: torch.Tensor, dcal: DeviceCalendar, bins: BinTable, q: float, wd: int, ws: int, ny: int,
+                      nx: int, rows: Optional[tuple] = None, cells: Optional[tuple] = None, wsp: Optional[dict] = None,
+                      binsb: Optional[torch.Tensor] = None, tails: Optional[dict] = None) -> Dict[str, object]:
+        """Approximate Hobday thresholds + extreme mask of an anomaly field (detect.py:1957-2004): through tails when
+        ``tails_plan`` takes the configuration, else through the bin matrix (``binsb``, made here when missing)."""
+        K = self.tails_plan(dcal, bins, q, wd, ws)
+        if K is not None:
+            tl = tails if tails is not None else self.tail_extract(anom, dcal, bins, K, wsp=wsp)
+            t = self.hobday_thresholds_tails(tl, anom, dcal, bins, q, wd, ws, ny, nx, rows=rows, wsp=wsp)
+            m = self.mask_ge_doy_tails(tl, anom, t["thr_doy_major"], dcal, bins, cells=cells, wsp=wsp)
+            keep = (tl, t["_keep"])
+        else:
+            if binsb is None:
+                binsb = self.digitize(anom, dcal, bins, wsp=wsp)
+            t = self.hobday_thresholds(binsb, anom, dcal, bins, q, wd, ws, ny, nx, rows=rows, wsp=wsp)
+            m = self.mask_ge_doy(anom, t["thr_doy_major"], dcal, cells=cells, wsp=wsp, binned=(binsb, bins))
+            keep = (binsb, t["_keep"])
+        return {"thr_doy_major": t["thr_doy_major"], "stats_dev": t["stats_dev"], "extreme": m["extreme"], "n_true": m["n_true"],
+                "path": "tails" if K is not None else "bins", "_keep": keep}
+
     # ------------------------------------------------------------------ stage a3 verdict
     def validation_summary(self, mask: torch.Tensor, invalid_count: torch.Tensor, cells: Optional[tuple] = None,
                            wsp: Optional[dict] = None) -> torch.Tensor:
@@ -291,22 +379,24 @@ class HotPath:
         ``own_rows=(row0, row1)``: the field is a latitude shard with overlap rows; thresholds and the
         mask are produced for the owned rows only (:mod:`marex_amd.dist`).
         """
-        a = self.shifting_baseline(x, dcal, W, S, bins, wsp=workspace)
+        K = self.tails_plan(dcal, bins, q, wd, ws)
+        a = self.shifting_baseline(x, dcal, W, S, bins if K is None else None, wsp=workspace)
         cells = None if own_rows is None else (own_rows[0] * nx, own_rows[1] * nx)
-        t = self.hobday_thresholds(a["bins"], a["out"], dcal, bins, q, wd, ws, ny, nx, rows=own_rows, wsp=workspace)
-        m = self.mask_ge_doy(a["out"], t["thr_doy_major"], dcal, cells=cells, wsp=workspace, binned=(a["bins"], bins))
+        h = self.hobday_approx(a["out"], dcal, bins, q, wd, ws, ny, nx, rows=own_rows, cells=cells, wsp=workspace,
+                               binsb=a.get("bins"))
         res = {
             "dat_anomaly": a["out"],
             "mask": a["mask"],
             "invalid_count": a["invalid_count"],
-            "thr_doy_major": t["thr_doy_major"],
-            "stats_dev": t["stats_dev"],
-            "extreme_events": m["extreme"],
-            "n_true": m["n_true"],
-            "_keep": (a["_keep"], t["_keep"], a.get("bins")),
+            "thr_doy_major": h["thr_doy_major"],
+            "stats_dev": h["stats_dev"],
+            "extreme_events": h["extreme"],
+            "n_true": h["n_true"],
+            "path": h["path"],
+            "_keep": (a["_keep"], h["_keep"]),
         }
         if transpose_thresholds:
-            res["thresholds"] = self.transpose(t["thr_doy_major"], wsp=workspace, name="thresholds")
+            res["thresholds"] = self.transpose(h["thr_doy_major"], wsp=workspace, name="thresholds")
         return res
 
     # ------------------------------------------------------------------ stage a13 (fixed baseline)

@@ -27,6 +27,6 @@ def hot():
     from marex_amd.csrc import build as _b
 
     _b.build(verbose=False)
-    from marex_amd.engine import HotPath
+    from marex_amd.detect import get_engine
 
-    return HotPath(0)
+    return get_engine(0)  # the engine the public API uses: options set on it in a test reach preprocess_data too

@@ -90,15 +90,15 @@ def test_global_approx_threshold(hot, pct):
     assert np.abs(got[ocean] - np.percentile(anom[:, ocean], pct, axis=0)).max() < 0.02
 
 
-def test_global_threshold_fallback_kernels_agree(hot, monkeypatch):
+def test_global_threshold_fallback_kernels_agree(hot):
     """Series longer than 65 535 steps use the first-generation kernels (32-bit counters); force them on a short series."""
     anom, cal = _anomalies(hot, "2002-01-01", 9 * 365 + 2, 5, 13)
     a = torch.from_numpy(anom).to(hot.device)
     new_e = hot.global_threshold(a, 95.0, "exact", None)["thr_f64"].cpu().numpy()
     new_a = hot.global_threshold(a, 95.0, "approximate", binning.hobday_bins())["thr_f64"].cpu().numpy()
-    monkeypatch.setenv("MAREX_GLOBAL_V1", "1")
-    old_e = hot.global_threshold(a, 95.0, "exact", None)["thr_f64"].cpu().numpy()
-    old_a = hot.global_threshold(a, 95.0, "approximate", binning.hobday_bins())["thr_f64"].cpu().numpy()
+    with hot.ctx.options(GLOBAL_V1=1):
+        old_e = hot.global_threshold(a, 95.0, "exact", None)["thr_f64"].cpu().numpy()
+        old_a = hot.global_threshold(a, 95.0, "approximate", binning.hobday_bins())["thr_f64"].cpu().numpy()
     assert np.array_equal(new_e, old_e, equal_nan=True) and np.array_equal(new_a, old_a, equal_nan=True)
 
 
@@ -120,7 +120,7 @@ def test_global_exact_with_ties_infinities_and_tiny_series(hot):
 
 
 @pytest.mark.parametrize("precision,max_anomaly", [(0.01, 5.0), (0.05, 2.0)])
-def test_mask_from_bins_equals_the_value_compare(hot, monkeypatch, precision, max_anomaly):
+def test_mask_from_bins_equals_the_value_compare(hot, precision, max_anomaly):
     """marex_mask_ge_doy_bins_f32 decides most samples from their bin; thresholds and anomalies placed exactly on bin edges,
     in the overflow bin, at +-inf and NaN must come out as `anom >= thr` does (detect.py:2003-2004)."""
     import torch
@@ -152,14 +152,24 @@ def test_mask_from_bins_equals_the_value_compare(hot, monkeypatch, precision, ma
     bd = hot.digitize(ad, dcal, bt)
     with np.errstate(invalid="ignore"):
         exp = anom >= thr[cal.doy - 1]
-    monkeypatch.setenv("MAREX_MASK_BINS", "1")  # (the automatic choice keeps the plain compare for series this short)
-    for cells in (None, (4, C - 8)):
-        got = hot.mask_ge_doy(ad, td, dcal, cells=cells, binned=(bd, bt))
+    with hot.ctx.options(MASK_BINS=1):  # (the automatic choice keeps the plain compare for series this short)
+        for cells in (None, (4, C - 8)):
+            got = hot.mask_ge_doy(ad, td, dcal, cells=cells, binned=(bd, bt))
+            hot.sync()
+            c0, c1 = cells or (0, C)
+            assert np.array_equal(got["extreme"].cpu().numpy().astype(bool)[:, c0:c1], exp[:, c0:c1])
+            assert int(got["n_true"].item()) == int(exp[:, c0:c1].sum())
+    with hot.ctx.options(MASK_BINS=0):  # the plain kernel behind the same entry point
+        got = hot.mask_ge_doy(ad, td, dcal, binned=(bd, bt))
         hot.sync()
-        c0, c1 = cells or (0, C)
-        assert np.array_equal(got["extreme"].cpu().numpy().astype(bool)[:, c0:c1], exp[:, c0:c1])
-        assert int(got["n_true"].item()) == int(exp[:, c0:c1].sum())
-    monkeypatch.setenv("MAREX_MASK_BINS", "0")  # the plain kernel behind the same entry point
-    got = hot.mask_ge_doy(ad, td, dcal, binned=(bd, bt))
-    hot.sync()
     assert np.array_equal(got["extreme"].cpu().numpy().astype(bool), exp)
+    # the mask from TAILS (marex_mask_ge_doy_tails_f32): same thresholds and anomalies, both tail lengths; buckets of 3
+    # rows fit any tail, so also cut the tails short (K = 16 of a 40-row bucket below) in test_gpu_tails.py
+    for K in (16, 32):
+        tl = hot.tail_extract(ad, dcal, bt, K)
+        for cells in (None, (4, C - 8)):
+            got = hot.mask_ge_doy_tails(tl, ad, td, dcal, bt, cells=cells)
+            hot.sync()
+            c0, c1 = cells or (0, C)
+            assert np.array_equal(got["extreme"].cpu().numpy().astype(bool)[:, c0:c1], exp[:, c0:c1]), K
+            assert int(got["n_true"].item()) == int(exp[:, c0:c1].sum())

@@ -55,9 +55,12 @@ _lo, _hi = (int(v) for v in os.environ.get("MAREX_FUZZ_SEEDS", "0:36").split(":"
 
 
 @pytest.mark.parametrize("seed", list(range(_lo, _hi)))
-def test_random_configuration_matches_the_oracle(hot, monkeypatch, seed):
+def test_random_configuration_matches_the_oracle(hot, seed):
     c = _case(seed)
-    monkeypatch.setenv("MAREX_MASK_BINS", "1" if seed % 2 else "-1")  # odd seeds: mask from the bin matrix whatever the length
+    # seed % 3: 0 = the representation the engine picks, 1 = tails forced (short tails re-read buckets), 2 = bin matrix
+    # (odd seeds there: mask from the bin matrix whatever the bucket length)
+    path = (None, "tails", "bins")[seed % 3]
     r = run_case(hot, c["start"], c["periods"], c["ny"], c["nx"], c["W"], c["S"], c["wd"], c["ws"], pct=c["pct"],
-                 unstructured=c["unstructured"], seed=c["seed"], mutate=c["mutate"])
+                 unstructured=c["unstructured"], seed=c["seed"], mutate=c["mutate"], path=path,
+                 opts={"MASK_BINS": 1} if seed % 2 else {})
     check_all(*r)

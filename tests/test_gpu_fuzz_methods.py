@@ -61,10 +61,13 @@ def test_random_method_pair_matches_the_oracle(hot, monkeypatch, seed):
     if mp == "approximate":
         kw.update(precision=prec, max_anomaly=maxa)
     monkeypatch.setenv("MAREX_BLOCKS", str(int(rng.choice([1, 1, 2, 3]))))
-    monkeypatch.setenv("MAREX_MASK_BINS", "1" if seed % 2 else "-1")
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        ds = marex_amd.preprocess_data(da, **kw, **extra)
+    hot.hobday_path = (None, "tails", "bins")[seed % 3]  # representation of the dayofyear histograms (same results)
+    try:
+        with hot.ctx.options(**({"MASK_BINS": 1} if seed % 2 else {})), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ds = marex_amd.preprocess_data(da, **kw, **extra)
+    finally:
+        hot.hobday_path = None
 
     cal = calendar.build_calendar(tm, window_year_baseline=W if ma == "shifting_baseline" else None)
     model = pmodel = None

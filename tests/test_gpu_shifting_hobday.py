@@ -25,7 +25,11 @@ def _same_f32(got, exp):
     return np.array_equal(got, exp, equal_nan=True)
 
 
-def run_case(hot, start, periods, ny, nx, W, S, wd, ws, pct=95.0, unstructured=False, seed=20240607, mutate=None):
+PATHS = ("tails", "bins")  # representation of the dayofyear histograms behind the thresholds: both must give the oracle's bits
+
+
+def run_case(hot, start, periods, ny, nx, W, S, wd, ws, pct=95.0, unstructured=False, seed=20240607, mutate=None, path=None,
+             opts=None):
     tm = calendar.daily_time_axis(start, periods)
     tab = synth.make_tables(tm, 0 if unstructured else ny, nx if not unstructured else ny * nx, seed, unstructured=unstructured)
     x = synth.synth_field(tab)
@@ -40,8 +44,15 @@ def run_case(hot, start, periods, ny, nx, W, S, wd, ws, pct=95.0, unstructured=F
     )
     dcal = hot.upload_calendar(cal)
     xd = torch.from_numpy(x).to(hot.device)
-    got = hot.shifting_hobday(xd, dcal, W=W, S=S, bins=bt, q=pct / 100.0, wd=wd, ws=(ws or 1), ny=gny, nx=gnx)
-    hot.sync()
+    hot.hobday_path = path
+    try:
+        with hot.ctx.options(**(opts or {})):
+            got = hot.shifting_hobday(xd, dcal, W=W, S=S, bins=bt, q=pct / 100.0, wd=wd, ws=(ws or 1), ny=gny, nx=gnx)
+            hot.sync()
+    finally:
+        hot.hobday_path = None
+    if path is not None:
+        assert got["path"] == path
     return x, cal, bt, exp, got
 
 
@@ -53,10 +64,10 @@ def check_all(x, cal, bt, exp, got):
     inv = got["invalid_count"].cpu().numpy()
     assert np.array_equal(inv, (~np.isfinite(x)).sum(axis=0))
     assert int(np.where(exp["mask"], inv, 0).max()) == v["max_invalid"]
-    # bins: device rows are dayofyear-sorted
-    bins_exp = orc.digitize_bins(exp["dat_anomaly"], bt.edges)[cal.doy_rows]
-    bins_got = HotPath.bins_to_rows(got["_keep"][2], x.shape[1]).cpu().numpy().view(np.uint16)
-    assert np.array_equal(bins_got, bins_exp)
+    if got["path"] == "bins":  # bins: device rows are dayofyear-sorted
+        bins_exp = orc.digitize_bins(exp["dat_anomaly"], bt.edges)[cal.doy_rows]
+        bins_got = HotPath.bins_to_rows(got["_keep"][1][0], x.shape[1]).cpu().numpy().view(np.uint16)
+        assert np.array_equal(bins_got, bins_exp)
     thr = got["thresholds"].cpu().numpy()
     assert _same_f32(thr, exp["thresholds"]), "thresholds differ from the oracle"
     ext = got["extreme_events"].cpu().numpy().astype(bool)
@@ -69,24 +80,27 @@ def check_all(x, cal, bt, exp, got):
         assert np.float32(st["min"]) == np.float32(exp["stats"]["min"])
 
 
-def test_gridded_default_windows(hot):
+@pytest.mark.parametrize("path", PATHS)
+def test_gridded_default_windows(hot, path):
     """30 yr x 12x16, W=15, S=21, wd=11, ws=5 (the reference defaults for gridded data)."""
-    r = run_case(hot, "1990-01-01", 30 * 365 + 8, 12, 16, 15, 21, 11, 5)
+    r = run_case(hot, "1990-01-01", 30 * 365 + 8, 12, 16, 15, 21, 11, 5, path=path)
     check_all(*r)
     ocean = r[3]["mask"]
     freq = r[3]["extreme_events"][:, ocean].mean()
     assert 0.04 < freq < 0.06  # the reference's own pin: 5 % +- 1 % (tests/conftest.py:215-231)
 
 
-def test_gridded_mid_year_start_small_windows(hot):
+@pytest.mark.parametrize("path", PATHS)
+def test_gridded_mid_year_start_small_windows(hot, path):
     """Series starting mid-year (partial first / last calendar years), W=5, even S, wd=5, ws=3."""
-    r = run_case(hot, "2001-07-19", 12 * 365 + 40, 9, 20, 5, 10, 5, 3, pct=90.0)
+    r = run_case(hot, "2001-07-19", 12 * 365 + 40, 9, 20, 5, 10, 5, 3, pct=90.0, path=path)
     check_all(*r)
 
 
-def test_unstructured_no_pooling(hot):
+@pytest.mark.parametrize("path", PATHS)
+def test_unstructured_no_pooling(hot, path):
     """(time, ncells) layout, C not a multiple of 4 or 256, no spatial pooling (detect.py:1361-1385)."""
-    r = run_case(hot, "1995-01-01", 20 * 365 + 5, 1, 405, 7, 21, 11, None, unstructured=True)
+    r = run_case(hot, "1995-01-01", 20 * 365 + 5, 1, 405, 7, 21, 11, None, unstructured=True, path=path)
     check_all(*r)
 
 
@@ -96,7 +110,8 @@ def test_generic_smoothing_widths(hot):
         check_all(*r)
 
 
-def test_weird_cells(hot):
+@pytest.mark.parametrize("path", PATHS)
+def test_weird_cells(hot, path):
     """NaN at t=0 but finite later ("land" by the t=0 rule), NaN gaps inside ocean cells, +-inf, constant cells."""
 
     def mutate(x):
@@ -107,80 +122,71 @@ def test_weird_cells(hot):
         x[:, ocean[3]] = np.float32(12.5)  # constant series -> anomaly 0 -> clamp to edges[3]
         x[:, ocean[4]] += np.float32(40.0) * (np.arange(x.shape[0]) % 7 == 0)  # spikes beyond max_anomaly
 
-    r = run_case(hot, "1998-03-01", 14 * 365 + 4, 6, 12, 6, 21, 11, 5, mutate=mutate)
+    r = run_case(hot, "1998-03-01", 14 * 365 + 4, 6, 12, 6, 21, 11, 5, mutate=mutate, path=path)
     check_all(*r)
 
 
-def test_threshold_kernel_variants(hot, monkeypatch):
-    """Band algorithm with other day-block lengths and the sliding-histogram kernel (16/32-bit counters,
-    other segment widths) all give the same bits as the default."""
-    envs = (
-        {"MAREX_THR_DD": "1"}, {"MAREX_THR_DD": "5"}, {"MAREX_THR_DD": "32"},
-        {"MAREX_THR_EXACT_PATH": "1"}, {"MAREX_THR_TILE": "32"}, {"MAREX_THR_TILE": "32", "MAREX_THR_EXACT_PATH": "1"},
-        {"MAREX_THR_TILE": "3216"}, {"MAREX_THR_TILE": "32", "MAREX_THR_DD": "7", "MAREX_THR_COARSE_PD": "5"},
-        {"MAREX_MASK_BINS": "1"}, {"MAREX_MASK_BINS": "1", "MAREX_MASK_VEC": "4"}, {"MAREX_MASK_BINS": "0"},
-        {"MAREX_THR_ALGO": "1"}, {"MAREX_THR_ALGO": "1", "MAREX_THR_U32": "1"},
-        {"MAREX_THR_ALGO": "1", "MAREX_THR_NW": "5"}, {"MAREX_THR_ALGO": "1", "MAREX_THR_NW": "64", "MAREX_THR_U32": "1"},
+def test_threshold_kernel_variants(hot):
+    """Bin-matrix kernels: band algorithm with other day-block lengths and the sliding-histogram kernel (16/32-bit counters,
+    other segment widths); tail kernels: other tiles / day-block lengths.  All give the same bits as the default."""
+    variants = (
+        ("bins", {"THR_DD": 1}), ("bins", {"THR_DD": 5}), ("bins", {"THR_DD": 32}),
+        ("bins", {"THR_EXACT_PATH": 1}), ("bins", {"THR_TILE": 32}), ("bins", {"THR_TILE": 32, "THR_EXACT_PATH": 1}),
+        ("bins", {"THR_TILE": 3216}), ("bins", {"THR_TILE": 32, "THR_DD": 7, "THR_COARSE_PD": 5}),
+        ("bins", {"MASK_BINS": 1}), ("bins", {"MASK_BINS": 1, "MASK_VEC": 4}), ("bins", {"MASK_BINS": 0}),
+        ("bins", {"THR_ALGO": 1}), ("bins", {"THR_ALGO": 1, "THR_U32": 1}),
+        ("bins", {"THR_ALGO": 1, "THR_NW": 5}), ("bins", {"THR_ALGO": 1, "THR_NW": 64, "THR_U32": 1}),
+        ("tails", {"THR_DD": 1}), ("tails", {"THR_DD": 5}), ("tails", {"THR_DD": 366}), ("tails", {"THR_TILE": 32}),
+        ("tails", {"THR_TILE": 32, "THR_DD": 7}), ("tails", {"THR_TILE": 32, "THR_TALL": 0}),
     )
-    for env in envs:
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        r = run_case(hot, "2003-01-01", 9 * 365 + 2, 19, 37, 4, 21, 11, 5)
+    for path, opts in variants:
+        r = run_case(hot, "2003-01-01", 9 * 365 + 2, 19, 37, 4, 21, 11, 5, path=path, opts=opts)
         check_all(*r)
-        for k in env:
-            monkeypatch.delenv(k)
 
 
-def test_threshold_edge_quantiles_and_windows(hot):
+@pytest.mark.parametrize("path", PATHS)
+def test_threshold_edge_quantiles_and_windows(hot, path):
     """q = 1.0 (searchsorted runs off the end), low q, wide day / spatial windows, tiny grids."""
     for pct, wd, ws, ny, nx in ((100.0, 11, 5, 6, 10), (60.0, 31, 3, 5, 9), (99.0, 5, 7, 20, 37), (95.0, 11, 5, 3, 4)):
-        r = run_case(hot, "2001-01-01", 11 * 365 + 3, ny, nx, 3, 21, wd, ws, pct=pct)
+        r = run_case(hot, "2001-01-01", 11 * 365 + 3, ny, nx, 3, 21, wd, ws, pct=pct, path=path)
         check_all(*r)
 
 
-def test_shifting_chunk_variants(hot, monkeypatch):
+def test_shifting_chunk_variants(hot):
     """Every dayofyear-chunk width / history placement (registers or LDS ring) of the anomaly kernel gives
-    identical bits, for W inside both ring capacities (8 and 16)."""
-    # MAREX_SHIFT_D / MAREX_SHIFT_FAST=0 route everything through the general kernel k_shifting
-    for ring, D in (("0", "1"), ("0", "4"), ("1", "2"), ("1", "4"), ("1", "8"), ("1", "fast-off")):
-        monkeypatch.setenv("MAREX_SHIFT_RING", ring)
-        if D == "fast-off":
-            monkeypatch.delenv("MAREX_SHIFT_D", raising=False)
-            monkeypatch.setenv("MAREX_SHIFT_FAST", "0")
-        else:
-            monkeypatch.setenv("MAREX_SHIFT_D", D)
-        r = run_case(hot, "2003-01-01", 9 * 365 + 2, 7, 21, 4, 21, 11, 5)
+    identical bits, for W inside both ring capacities (8 and 16); with and without the fused bin matrix."""
+    # SHIFT_D / SHIFT_FAST=0 route everything through the general kernel k_shifting
+    for ring, D in ((0, 1), (0, 4), (1, 2), (1, 4), (1, 8), (1, "fast-off")):
+        opts = {"SHIFT_RING": ring}
+        opts.update({"SHIFT_FAST": 0} if D == "fast-off" else {"SHIFT_D": D})
+        r = run_case(hot, "2003-01-01", 9 * 365 + 2, 7, 21, 4, 21, 11, 5, opts=opts, path="bins")
         check_all(*r)
-        r = run_case(hot, "1990-06-01", 20 * 365 + 5, 5, 9, 13, 21, 11, 3)
+        r = run_case(hot, "1990-06-01", 20 * 365 + 5, 5, 9, 13, 21, 11, 3, opts=opts, path="tails")
         check_all(*r)
-    monkeypatch.delenv("MAREX_SHIFT_D", raising=False)
-    monkeypatch.delenv("MAREX_SHIFT_FAST", raising=False)
-    monkeypatch.delenv("MAREX_SHIFT_RING")
 
 
-def test_fast_anomaly_kernel_instances_and_general_fallbacks(hot):
+@pytest.mark.parametrize("path", PATHS)
+def test_fast_anomaly_kernel_instances_and_general_fallbacks(hot, path):
     """Every instantiated W of k_shift_fast, a W without an instance (general kernel), even W (real division),
     series starting mid-chunk and ending mid-year (edge years, partial chunks)."""
     for W, start, periods in ((3, "2004-01-01", 8 * 365 + 2), (6, "2001-03-17", 11 * 365 + 100), (7, "2000-01-01", 12 * 365 + 3),
                               (10, "1996-01-01", 16 * 365 + 4), (13, "1990-06-01", 20 * 365 + 5), (8, "1999-01-01", 13 * 365 + 3),
                               (16, "1990-01-01", 21 * 365 + 5)):
-        r = run_case(hot, start, periods, 5, 9, W, 21, 11, 3)
+        r = run_case(hot, start, periods, 5, 9, W, 21, 11, 3, path=path)
         check_all(*r)
 
 
-def test_long_buckets_pick_the_big_tile(hot):
-    """28 output years per dayofyear bucket on a 20x40 grid: the threshold entry point switches to 32x32 tiles."""
-    r = run_case(hot, "1985-01-01", 32 * 365 + 8, 20, 40, 4, 21, 11, 5)
+@pytest.mark.parametrize("path", PATHS)
+def test_long_buckets_pick_the_big_tile(hot, path):
+    """28 output years per dayofyear bucket on a 20x40 grid: the threshold entry points switch to 32x32 tiles."""
+    r = run_case(hot, "1985-01-01", 32 * 365 + 8, 20, 40, 4, 21, 11, 5, path=path)
     check_all(*r)
 
 
-@pytest.mark.parametrize("ny,nx,env", [(30, 52, {}), (31, 27, {"MAREX_THR_EXACT_PATH": "1"}), (61, 53, {"MAREX_THR_DD": "9"}),
-                                       (30, 52, {"MAREX_THR_TALL": "0"})])
-def test_tall_tile_for_bands_it_tiles_better(hot, monkeypatch, ny, nx, env):
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("ny,nx,opts", [(30, 52, {}), (31, 27, {"THR_EXACT_PATH": 1}), (61, 53, {"THR_DD": 9}), (30, 52, {"THR_TALL": 0})])
+def test_tall_tile_for_bands_it_tiles_better(hot, path, ny, nx, opts):
     """34 x 30 tiles (1020 cells on 1024 threads, four spare lanes) replace 32 x 32 where they need fewer tiles -- e.g. 30
     rows: one row of tiles instead of two; same bits as the oracle, also on the exact path and with short day blocks."""
-    monkeypatch.setenv("MAREX_THR_TILE", "32")
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    r = run_case(hot, "2001-01-01", 8 * 365 + 2, ny, nx, 3, 21, 11, 5)
+    r = run_case(hot, "2001-01-01", 8 * 365 + 2, ny, nx, 3, 21, 11, 5, path=path, opts=dict(opts, THR_TILE=32))
     check_all(*r)

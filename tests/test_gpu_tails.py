@@ -1,0 +1,156 @@
+"""GPU: the tail kernels (marex_tail_extract_f32, marex_hobday_thresholds_tails_f32, marex_mask_ge_doy_tails_f32).
+
+Tails are an internal representation (include/marex_hip.h, TAILS): what is checked against the oracle is what the
+reference defines -- thresholds and the extreme mask -- plus the tails themselves against a NumPy statement of their
+definition.  The cases force the parts of the kernels that ordinary fields rarely reach: tails much shorter than the
+number of samples above the band (buckets re-read from the anomalies), thresholds that drift across many bands over
+the year and jump between neighbouring cells (band rebuilds, extra passes), values beyond the edge table.
+"""
+import numpy as np
+import pytest
+import torch
+
+from marex_amd import binning, calendar, synth
+from marex_amd.engine import HotPath
+from oracle import marex_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def tails_reference(anom, cal, edges, K):
+    """NumPy statement of the tails of ``anom`` [T_out, C]: keys[366, K, C] (descending, 0 = empty), aux[366, C]."""
+    nb = edges.size - 1
+    T_out, C = anom.shape
+    with np.errstate(invalid="ignore"):
+        bins = np.digitize(anom, edges) - 1
+        over = (anom >= edges[-1]) & ~np.isnan(anom)
+    keys = np.zeros((366, K, C), dtype=np.uint16)
+    aux = np.zeros((366, C), dtype=np.uint16)
+    for d in range(366):
+        rows = cal.doy_rows[cal.doy_start[d]:cal.doy_start[d + 1]]
+        if rows.size == 0:
+            continue
+        b = bins[rows]                                    # [n, C]
+        valid = b < nb
+        k = np.where(valid, ((b + 1) << 7) | np.arange(rows.size)[:, None], 0).astype(np.uint16)
+        k = -np.sort(-k.astype(np.int32), axis=0)         # descending
+        n = min(K, rows.size)
+        keys[d, :n] = k[:n].astype(np.uint16)
+        aux[d] = valid.sum(axis=0).astype(np.uint16) | np.where(over[rows].any(axis=0), 0x8000, 0).astype(np.uint16)
+    return keys, aux
+
+
+def device_tails_to_keys(tl, C):
+    t = tl["tails"].cpu().numpy().view(np.uint16)          # [366, K/8, C, 8]
+    K = tl["K"]
+    return np.ascontiguousarray(t.transpose(0, 1, 3, 2)).reshape(366, K, C), tl["aux"].cpu().numpy().view(np.uint16)
+
+
+def make_anomalies(T_years=12, C=300, seed=3, start="2000-01-01", sigma=0.8):
+    rng = np.random.default_rng(seed)
+    tm = calendar.daily_time_axis(start, T_years * 365 + 3)
+    cal = calendar.build_calendar(tm)
+    anom = rng.normal(0, sigma, (len(tm), C)).astype(np.float32)
+    return tm, cal, anom, rng
+
+
+@pytest.mark.parametrize("K", [16, 32])
+@pytest.mark.parametrize("years,C", [(12, 300), (40, 257), (3, 1024)])
+def test_tail_extract_matches_its_definition(hot, K, years, C):
+    tm, cal, anom, rng = make_anomalies(years, C)
+    pick = rng.random(anom.shape)
+    anom[pick < 0.02] = np.nan
+    anom[(pick > 0.02) & (pick < 0.025)] = np.inf
+    anom[(pick > 0.025) & (pick < 0.03)] = -np.inf
+    anom[(pick > 0.03) & (pick < 0.035)] = 7.5                      # beyond the table: dropped from the counts, flagged
+    anom[:, 5] = np.nan                                             # land
+    anom[:, 6] = 0.25                                               # all samples in one bin: ties broken by position
+    bt = binning.hobday_bins()
+    dcal = hot.upload_calendar(cal)
+    tl = hot.tail_extract(torch.from_numpy(anom).to(hot.device), dcal, bt, K)
+    hot.sync()
+    keys, aux = device_tails_to_keys(tl, C)
+    ekeys, eaux = tails_reference(anom, cal, bt.edges, K)
+    assert np.array_equal(aux, eaux)
+    assert np.array_equal(keys, ekeys)
+
+
+def _thr_case(hot, anom, cal, bt, pct, wd, ws, ny, nx, K, opts=None, rows=None):
+    dcal = hot.upload_calendar(cal)
+    ad = torch.from_numpy(anom).to(hot.device)
+    tl = hot.tail_extract(ad, dcal, bt, K)
+    hot.ctx.debug_counters(reset=True)
+    with hot.ctx.options(**(opts or {})):
+        t = hot.hobday_thresholds_tails(tl, ad, dcal, bt, pct / 100.0, wd, ws or 1, ny, nx, rows=rows)
+        m = hot.mask_ge_doy_tails(tl, ad, t["thr_doy_major"], dcal, bt)
+        hot.sync()
+    counters = hot.ctx.debug_counters(reset=True)
+    exp_thr, exp_stats = orc.hobday_thresholds_approx(anom, cal.doy_out, pct / 100.0, wd, ws, bt.edges, bt.centres, ny, nx)
+    exp_ext = orc.mask_ge_doy(anom, exp_thr, cal.doy_out)
+    thr = t["thr_doy_major"].cpu().numpy().T
+    if rows is not None:
+        sl = slice(rows[0] * nx, rows[1] * nx)
+        assert np.array_equal(thr[sl], exp_thr[sl], equal_nan=True)
+        return counters
+    assert np.array_equal(thr, exp_thr, equal_nan=True), "thresholds differ from the oracle"
+    assert np.array_equal(m["extreme"].cpu().numpy().astype(bool), exp_ext), "mask differs from the oracle"
+    assert int(m["n_true"].item()) == int(exp_ext.sum())
+    st = HotPath.decode_thr_stats(t["stats_dev"])
+    assert st["n_too_low"] == exp_stats["n_too_low"] and st["n_too_high"] == exp_stats["n_too_high"]
+    return counters
+
+
+@pytest.mark.parametrize("K", [16, 32])
+def test_short_tails_reread_their_buckets(hot, K):
+    """40 samples per bucket, q = 0.6: 16 of them lie above the quantile, far more than a 16-key tail holds and close to
+    what a 32-key tail holds -- the threshold kernel has to fetch the rest from the anomalies, the mask kernel too."""
+    tm, cal, anom, rng = make_anomalies(40, 12 * 20, seed=11)
+    anom[:, 7] = np.nan
+    bt = binning.hobday_bins()
+    c = _thr_case(hot, anom, cal, bt, 60.0, 11, 5, 12, 20, K)
+    assert c[1] > 0, c                # buckets re-read from the anomalies by the threshold kernel
+    if K == 16:
+        assert c[4] > 0, c            # 16 keys do not reach down to the 60th percentile: mask groups decided on the values
+    c = _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 12, 20, K)
+    if K == 32:
+        assert c[1] == 0, c           # K = 32 holds the top 80 % of a 40-sample bucket: no re-reads at p95
+
+
+@pytest.mark.parametrize("tile", [16, 32])
+def test_seasonal_and_patchy_thresholds_move_the_band(hot, tile):
+    """The 95th percentile swings by 2.4 K over the year (3.75 bands of 64 bins) and differs by 1.5 K between the two halves
+    of the grid (more than two bands inside one tile): the band is rebuilt as the walk goes and extra passes answer the cells
+    it cannot hold at once -- same bits as the oracle."""
+    tm, cal, _, rng = make_anomalies(30, 40 * 36, seed=5)
+    doy = cal.doy_out.astype(np.float64)
+    amp = 0.5 + 0.45 * np.sin(2 * np.pi * (doy - 40) / 366.0)                   # sigma 0.05 .. 0.95 K
+    field = rng.normal(0, 1, (cal.T_out, 40 * 36)).astype(np.float32) * amp[:, None].astype(np.float32)
+    field = field.reshape(-1, 40, 36)
+    field[:, :, 18:] *= np.float32(2.2)                                          # patchy: right half far more variable
+    field[:, 20:, :] += np.float32(0.3)
+    anom = np.ascontiguousarray(field.reshape(cal.T_out, -1))
+    bt = binning.hobday_bins()
+    c = _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 40, 36, 32, opts={"THR_TILE": tile, "THR_DD": 366})
+    assert c[0] > c[3] / 366 and c[2] > 0, c       # more rebuilds than one per block; stragglers needed extra passes
+    _thr_case(hot, anom, cal, bt, 90.0, 5, 3, 40, 36, 32, opts={"THR_TILE": tile})
+
+
+def test_owned_rows_and_unstructured(hot):
+    tm, cal, anom, rng = make_anomalies(20, 23 * 31, seed=8)
+    bt = binning.hobday_bins()
+    _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 23, 31, 32, rows=(2, 19))
+    _thr_case(hot, anom, cal, bt, 95.0, 11, 7, 23, 31, 32)
+    _thr_case(hot, anom[:, :700], cal, bt, 95.0, 11, None, 0, 700, 32)            # no pooling, C not a multiple of 256
+    _thr_case(hot, anom[:, :700], cal, bt, 100.0, 21, None, 0, 700, 16)           # q = 1: quantile runs off the table end
+
+
+def test_constant_and_extreme_data(hot):
+    """All samples in one bin (ties), everything below the table's first edge, everything beyond the last (empty histograms)."""
+    tm, cal, anom, rng = make_anomalies(18, 10 * 16, seed=2)
+    anom[:, 0:40] = np.float32(0.0)            # constant -> thresholds clamp to edges[3], warning counter
+    anom[:, 40:80] = np.float32(-3.0)          # everything in bin 0
+    anom[:, 80:120] = np.float32(9.0)          # nothing countable: NaN thresholds, mask decided on the values
+    anom[:, 120:130] = np.float32(4.985)       # the last countable bins: above the upper warning bound
+    bt = binning.hobday_bins()
+    _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 10, 16, 32)
+    _thr_case(hot, anom, cal, bt, 95.0, 11, 1, 10, 16, 16)
