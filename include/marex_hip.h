@@ -72,9 +72,9 @@ int marex_sync(marex_ctx* ctx);
  * these calls change it -- nothing reads the environment at launch time.  name == NULL clears every option. */
 int marex_set_option(marex_ctx* ctx, const char* name, int value);
 int marex_clear_option(marex_ctx* ctx, const char* name);
-/* Event counters of the tail kernels (host uint64[8], synchronises the stream): [0] column rebuilds, [1] buckets re-read
- * from the anomalies by the threshold kernel, [2] extra passes for stragglers, [3] days walked (per tile and block),
- * [4] (4-cell, dayofyear) groups the mask kernel decided on the anomalies.  reset != 0 zeroes them afterwards. */
+/* Event counters of the tail kernels (host uint64[8], synchronises the stream): [0] column rebuilds, [1] unused, [2] extra passes for stragglers, [3] days walked (per tile and block),
+ * [4] (4-cell, dayofyear) groups the mask kernel decided on the anomalies, [5..7] phase timers of -DMAREX_STAMPS builds.
+ * reset != 0 zeroes them afterwards. */
 int marex_debug_counters(marex_ctx* ctx, uint64_t* out8, int reset);
 
 /* per-kernel device timing with HIP events on the context's stream (used by bench.py) */
@@ -159,35 +159,38 @@ int marex_mask_ge_doy_bins_f32(marex_ctx* ctx, const float* anom, const uint16_t
 /*
  * TAILS: the default representation of the day-of-year histograms of the approximate Hobday method
  * (marEx/detect.py:2622-2648: np.digitize + the flox 2-D count by (dayofyear, bin)).  Only the upper end of a histogram
- * decides a high quantile, so instead of a dense (366 x nb) count per cell the device keeps, per (dayofyear, cell)
- * bucket, its K largest samples as sorted 16-bit keys plus the number of counted samples:
+ * decides a high quantile, so instead of a dense (366 x nb) count per cell the device keeps the samples of every
+ * (dayofyear, cell) bucket as 16-bit keys in short lists that are sorted descending; consumers read the top of each list
+ * and stop at the first key they do not need:
  *   key = ((bin + 1) << 7) | pos    bin = np.digitize(anom, edges) - 1 (< nb <= 511), pos = index of the sample inside the
- *                                   bucket (output row doy_rows[doy_start[d] + pos], < 128); 0 = empty slot
- *   tails  uint16, [366][K/8][C][8] the K largest keys of bucket (d, c), descending, in chunks of 8 (16 bytes)
- *   aux    uint16, [366][C]         bits 0..9: samples with bin < nb (what the reference's histogram counts);
+ *                                   bucket (output row doy_rows[doy_start[d] + pos], < 128); 0 = empty slot; samples the
+ *                                   reference's histogram drops (NaN, >= edges[nb]) have no key
+ *   lists  uint16, [366][NPER][2][C][8]   chunk j (0: the 8 largest, 1: the rest) of list p of bucket (d, c); a bucket's keys
+ *                                   are partitioned over NPER = marex_tail_lists(max_bucket) = ceil(max_bucket / 16) lists
+ *                                   of <= 16 keys, each sorted descending (which keys share a list is up to the producer)
+ *   aux    uint16, [366][C]         bits 0..9: number of keys of the bucket (= the samples the reference counts);
  *                                   bit 15: the bucket holds a non-NaN value >= edges[nb]
  * marex_tail_extract_f32 builds them from any anomaly field (rows grouped by dayofyear through doy_start / doy_rows,
- * max_bucket = rows of the largest dayofyear, <= 128); K is 16 or 32.  Consumers that run out of keys while they still
- * need samples re-read that bucket's anomalies (keys are unique, so "not in the tail" = "key below the last tail key"):
- * results do not depend on K, only the speed does.
+ * max_bucket = rows of the largest dayofyear, <= 128).  The shifting-baseline anomaly kernel can emit them itself
+ * (marex_shifting_baseline_tails_f32).
  */
+int marex_tail_lists(int max_bucket);
 int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
-                           const int32_t* doy_rows, int max_bucket, const float* edges, int nb, int K, void* tails,
-                           uint16_t* aux);
+                           const int32_t* doy_rows, int max_bucket, const float* edges, int nb, void* lists, uint16_t* aux);
 
 /* Day-of-year thresholds from tails: same result as marex_hobday_thresholds_f32 (detect.py:2638-2732, 2465-2559: pooled
  * counts, count-interpolated quantile, NaN where the first kept anomaly is NaN, clamp and warning statistics), arguments as
- * there plus the tails and the anomaly field they were extracted from (`anom`, [T_out, C], its row 0 is first_anom).
- * Needs nb <= 511, max_bucket <= 128, ws <= 7 and max_bucket*wd*ws*ws <= 65535 (else -4: use the bin-matrix entry point). */
-int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* tails, const uint16_t* aux, int K, const float* anom,
-                                      int64_t T_out, int64_t C, int ny, int nx, const int32_t* doy_start,
-                                      const int32_t* doy_rows, int max_bucket, const float* edges, const float* centres,
-                                      int nb, double q, int wd, int ws, float lower_bound, float upper_bound, int row0,
-                                      int row1, float* thr_doy_major, marex_thr_stats* stats);
+ * there plus the tails and the anomaly field they belong to (`anom`, [T_out, C]: its row 0 is first_anom).
+ * Needs nb <= 511, max_bucket <= 128, ws <= 7, max_bucket*wd*ws*ws <= 65535 and C <= 2^24 (else -4: use the bin-matrix
+ * entry point). */
+int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, const float* anom, int64_t T_out,
+                                      int64_t C, int ny, int nx, int max_bucket, const float* centres, int nb, double q, int wd,
+                                      int ws, float lower_bound, float upper_bound, int row0, int row1, float* thr_doy_major,
+                                      marex_thr_stats* stats);
 
 /* The extreme mask from tails: same result as marex_mask_ge_doy_f32 (detect.py:2003-2004, 833-835) without reading the
- * anomalies, except for samples in the threshold's own bin and for buckets whose tail does not reach below the threshold. */
-int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* tails, const uint16_t* aux, int K, const float* anom,
+ * anomalies, except for samples in the threshold's own bin and for buckets holding values beyond the edge table. */
+int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, int max_bucket, const float* anom,
                                 const float* edges, int nb, const float* thr_doy_major, const int32_t* doy_start,
                                 const int32_t* doy_rows, int64_t T_out, int64_t C, int64_t c0, int64_t c1, uint8_t* extreme,
                                 unsigned long long* n_true);

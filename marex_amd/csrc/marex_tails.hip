@@ -3,39 +3,99 @@
 #include "marex_tails.hip.h"
 
 // ------------------------------------------------------------------------------------------------
-// K_X: tails of an anomaly field (the counting stage of detect.py:2622-2648 in the form the threshold and mask
-// kernels consume, see marex_tails.hip.h).  Thread = cell, two neighbouring dayofyears at a time as packed pairs:
-// 16 rows of both buckets in flight, np.digitize, keys, a 16-key sorting network and a merge into the K best so far.
-// Reads every anomaly once (coalesced 256-byte row segments per wave, like the mask kernel); the VALU work
-// (~25 instructions per sample) hides under the HBM stream.
+// device helpers shared by the three kernels
 // ------------------------------------------------------------------------------------------------
-template <int K>
+typedef __amdgpu_buffer_rsrc_t tl_rsrc_t;
+__device__ __forceinline__ tl_rsrc_t tl_make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+// one 16-byte chunk: wave-uniform base (SGPRs), 32-bit lane byte offset, 32-bit uniform byte offset
+__device__ __forceinline__ uint4 tl_load_chunk(tl_rsrc_t r, unsigned voff, unsigned soff) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ unsigned pk_sub_sat_u16(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_add_u16(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_sub_u16(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// number of keys of a chunk that are > lim (lim replicated in both halves of lim_rep); the chunk is sorted descending, so
+// these are its FIRST keys.  10 instructions for 8 keys.
+__device__ __forceinline__ int tl_count_above(const uint4& ch, unsigned lim_rep) {
+    const unsigned one = 0x00010001u;
+    const unsigned m0 = pk_min_u16(pk_sub_sat_u16(ch.x, lim_rep), one), m1 = pk_min_u16(pk_sub_sat_u16(ch.y, lim_rep), one);
+    const unsigned m2 = pk_min_u16(pk_sub_sat_u16(ch.z, lim_rep), one), m3 = pk_min_u16(pk_sub_sat_u16(ch.w, lim_rep), one);
+    const unsigned s = (m0 + m1) + (m2 + m3);
+    return (int)((s & 0xFFFFu) + (s >> 16));
+}
+// key u (0..7) of a chunk; u is a compile-time constant at every call
+__device__ __forceinline__ unsigned tl_key(const uint4& ch, int u) {
+    const unsigned w = u < 2 ? ch.x : (u < 4 ? ch.y : (u < 6 ? ch.z : ch.w));
+    return (u & 1) ? (w >> 16) : (w & 0xFFFFu);
+}
+// bin + 1 of key u: bits 7..15 of its half
+__device__ __forceinline__ int tl_bin1(const uint4& ch, int u) {
+    const unsigned w = u < 2 ? ch.x : (u < 4 ? ch.y : (u < 6 ? ch.z : ch.w));
+    return (u & 1) ? (int)(w >> (16 + TAIL_POS_BITS)) : (int)__builtin_amdgcn_ubfe(w, TAIL_POS_BITS, 16 - TAIL_POS_BITS);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_X: tails of an anomaly field (the counting stage of detect.py:2622-2648 in the form the threshold and mask kernels
+// consume, see marex_tails.hip.h).  Thread = cell, two neighbouring dayofyears at a time as packed pairs: 16 rows of
+// both buckets in flight, np.digitize, keys, one 16-key sorting network per list.  Used for the anomaly methods whose
+// kernels do not emit tails themselves (fixed baselines, detrending, standardised anomalies, identify_extremes).
+// Reads every anomaly once: coalesced 256-byte row segments per wave, like the mask kernel.
+// ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ doy_start, const int* __restrict__ doy_rows,
-               const float* __restrict__ edges, int nb, uint4* __restrict__ tails, unsigned short* __restrict__ aux) {
+               const float* __restrict__ edges, int nb, int NPER, uint4* __restrict__ lists, unsigned short* __restrict__ aux) {
     extern __shared__ float e[];  // [nb + 1]
-    constexpr int KC = K / 8;
     const int tid = threadIdx.x;
     for (int i = tid; i <= nb; i += 256) e[i] = edges[i];
     __syncthreads();
-    const bool arange_tab = edges_are_arange(e, nb);
-    const float inv_width = (float)(nb - 1) / (e[nb] - e[1]);
     const float e_first = e[1], e_delta = e[2] - e[1], e_last = e[nb];
+    const float inv_width = (float)(nb - 1) / (e_last - e_first);
+    // arange table (NumPy float32 arange, contract C4) whose fused guess is provably within one bin: the lean digitize of
+    // the anomaly kernel; any other increasing table: the general search
+    bool lean = edges_are_arange(e, nb);
+    {
+        const double m = fabs((double)e_first) > fabs((double)e_last) ? fabs((double)e_first) : fabs((double)e_last);
+        lean = lean && e_delta > 0.f && ((double)nb + 2.0 * m / (double)e_delta) * (1.0 / 1048576.0) < 1.0 / 256.0;
+    }
+    const float c0 = (1.0f - e_first * inv_width) - 0.0078125f, nbm1f = (float)(nb - 1);
+    auto digit = [&](float a) -> int {
+        if (lean) {
+            const float f = __builtin_fmaf(a, inv_width, c0);
+            const float t = __builtin_amdgcn_fmed3f(__builtin_floorf(f), 0.0f, nbm1f);
+            const float ehi = e_first + t * e_delta;  // edges[t + 1], the table's own arithmetic (separately rounded)
+            const int k = (int)t + (a >= ehi ? 1 : 0);
+            return (a == a) ? k : nb;
+        }
+        return digitize_bin(a, e, nb, inv_width);
+    };
     const long c = (long)blockIdx.x * 256 + tid;
     const bool active = c < C;
     const long cidx = active ? c : C - 1;
     const int npairs = NDOY / 2;
     const int pA = (int)blockIdx.y * npairs / (int)gridDim.y, pB = ((int)blockIdx.y + 1) * npairs / (int)gridDim.y;
-    for (int p = pA; p < pB; ++p) {
-        const int d0 = 2 * p, d1 = d0 + 1;
+    for (int pp = pA; pp < pB; ++pp) {
+        const int d0 = 2 * pp, d1 = d0 + 1;
         const int s0 = doy_start[d0], n0 = doy_start[d0 + 1] - s0;
         const int s1 = doy_start[d1], n1 = doy_start[d1 + 1] - s1;
-        const int nmax = n0 > n1 ? n0 : n1;
-        unsigned top[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) top[i] = 0u;
         unsigned cnt0 = 0, cnt1 = 0, ovf0 = 0, ovf1 = 0;
-        for (int r = 0; r < nmax; r += 16) {
+        for (int p = 0; p < NPER; ++p) {
+            const int r = p * TAIL_LIST;
             float va[16], vb[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -47,8 +107,7 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int pos = r + u;
-                const int ba = arange_tab ? digitize_arange(va[u], e_first, e_delta, e_last, nb, inv_width) : digitize_bin(va[u], e, nb, inv_width);
-                const int bb = arange_tab ? digitize_arange(vb[u], e_first, e_delta, e_last, nb, inv_width) : digitize_bin(vb[u], e, nb, inv_width);
+                const int ba = digit(va[u]), bb = digit(vb[u]);
                 const unsigned ka = ba < nb ? tail_key(ba, pos) : 0u, kb = bb < nb ? tail_key(bb, pos) : 0u;
                 cnt0 += ba < nb;
                 cnt1 += bb < nb;
@@ -56,41 +115,45 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
                 ovf1 |= vb[u] >= e_last;
                 nw[u] = ka | (kb << 16);
             }
-            bitonic_sort_desc<16>(nw);
-            tail_merge<K, 16>(top, nw);
+            sort16_desc(nw);
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    uint4 w0, w1;
+                    unsigned* a = reinterpret_cast<unsigned*>(&w0);
+                    unsigned* b = reinterpret_cast<unsigned*>(&w1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned x = nw[8 * j + 2 * i], y = nw[8 * j + 2 * i + 1];
+                        a[i] = (x & 0xFFFFu) | (y << 16);
+                        b[i] = (x >> 16) | (y & 0xFFFF0000u);
+                    }
+                    lists[(((size_t)d0 * NPER + p) * 2 + j) * C + c] = w0;
+                    lists[(((size_t)d1 * NPER + p) * 2 + j) * C + c] = w1;
+                }
+            }
         }
         if (active) {
-#pragma unroll
-            for (int j = 0; j < KC; ++j) {
-                uint4 w0, w1;
-                unsigned* a = reinterpret_cast<unsigned*>(&w0);
-                unsigned* b = reinterpret_cast<unsigned*>(&w1);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned x = top[8 * j + 2 * i], y = top[8 * j + 2 * i + 1];
-                    a[i] = (x & 0xFFFFu) | (y << 16);
-                    b[i] = (x >> 16) | (y & 0xFFFF0000u);
-                }
-                tails[((size_t)d0 * KC + j) * C + c] = w0;
-                tails[((size_t)d1 * KC + j) * C + c] = w1;
-            }
             aux[(size_t)d0 * C + c] = (unsigned short)(cnt0 | (ovf0 ? 0x8000u : 0u));
             aux[(size_t)d1 * C + c] = (unsigned short)(cnt1 | (ovf1 ? 0x8000u : 0u));
         }
     }
 }
 
+static int tails_nper(int max_bucket) { return (max_bucket + TAIL_LIST - 1) / TAIL_LIST; }
+
+extern "C" int marex_tail_lists(int max_bucket) { return (max_bucket < 1 || max_bucket > TAIL_MAX_BUCKET) ? -1 : tails_nper(max_bucket); }
+
 extern "C" int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
-                                      const int32_t* doy_rows, int max_bucket, const float* edges, int nb, int K,
-                                      void* tails, uint16_t* aux) {
+                                      const int32_t* doy_rows, int max_bucket, const float* edges, int nb, void* lists,
+                                      uint16_t* aux) {
     if (!ctx) return -1;
-    if (!anom || !doy_start || !doy_rows || !edges || !tails || !aux || T_out <= 0 || C <= 0)
+    if (!anom || !doy_start || !doy_rows || !edges || !lists || !aux || T_out <= 0 || C <= 0)
         return fail(ctx, -1, "marex_tail_extract_f32: null pointer or empty shape");
     if (nb < 4 || nb > TAIL_MAX_NB) return fail(ctx, -4, "marex_tail_extract_f32: nb must be in 4..%d", TAIL_MAX_NB);
     if (max_bucket < 1 || max_bucket > TAIL_MAX_BUCKET)
         return fail(ctx, -4, "marex_tail_extract_f32: dayofyear buckets must hold 1..%d rows", TAIL_MAX_BUCKET);
-    if (K != 16 && K != 32) return fail(ctx, -1, "marex_tail_extract_f32: K must be 16 or 32");
-    if (((uintptr_t)tails & 15) != 0 || (C % 1) != 0) return fail(ctx, -1, "marex_tail_extract_f32: tails must be 16-byte aligned");
+    if (((uintptr_t)lists & 15) != 0) return fail(ctx, -1, "marex_tail_extract_f32: lists must be 16-byte aligned");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const unsigned ncb = (unsigned)((C + 255) / 256);
     unsigned chunks = (2048 + ncb - 1) / ncb;  // enough workgroups to fill the chip whatever the number of cells
@@ -98,12 +161,8 @@ extern "C" int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t
     const size_t lds = (size_t)(nb + 1) * sizeof(float);
     {
         LaunchTimer lt(ctx, MAREX_K_TAILS);
-        if (K == 16)
-            hipLaunchKernelGGL(k_tail_extract<16>, dim3(ncb, chunks), dim3(256), lds, ctx->stream, anom, (long)C, doy_start, doy_rows,
-                               edges, nb, reinterpret_cast<uint4*>(tails), aux);
-        else
-            hipLaunchKernelGGL(k_tail_extract<32>, dim3(ncb, chunks), dim3(256), lds, ctx->stream, anom, (long)C, doy_start, doy_rows,
-                               edges, nb, reinterpret_cast<uint4*>(tails), aux);
+        hipLaunchKernelGGL(k_tail_extract, dim3(ncb, chunks), dim3(256), lds, ctx->stream, anom, (long)C, doy_start, doy_rows, edges,
+                           nb, tails_nper(max_bucket), reinterpret_cast<uint4*>(lists), aux);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -116,10 +175,8 @@ extern "C" int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t
 // dayofyears, walked in order.  Lane = cell: its private LDS column holds the CUMULATIVE counts of its own wd-day window
 // over the levels of a band of 64 bins [B0, B0 + 64): level 0 = everything below the band, level k = bin B0 + k - 1,
 // level 65 = everything above (uint16, two levels per dword).  A day's update touches only the keys of the entering and
-// the leaving bucket that lie inside the band -- a handful out of the tail, found by walking the sorted chunks until a
-// key drops below B0; all other samples of the bucket are one number added to level 0 (aux count minus the keys used).
-// A tail that ends inside the band (more samples than keys, last key still >= B0) sends that lane to the bucket's
-// anomalies for the keys below its last one: exact for any data, rare by the choice of K.
+// the leaving bucket that lie inside the band: the first keys of every sorted list (counted with packed 16-bit
+// arithmetic, no search); all other samples of the bucket are one number added to level 0 (aux count minus the keys used).
 // Output lanes get pooled cumulative counts by summing the (2P+1)^2 neighbour columns (integers => exact) and walk
 // from the previous day's level.
 //
@@ -127,28 +184,33 @@ extern "C" int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t
 // rebuilds its columns (wd buckets, cheap on tails) around a band further down / up and answers the stragglers, and after
 // every day the band is re-centred on the day's range of quantile bins whenever that range comes within MARGIN bins
 // of an edge.  Seasonal drift of the thresholds therefore costs a rebuild every few weeks of the walk, not a slower path.
+//
+// The kernel is bound by instruction ISSUE (a CDNA4 SIMD starts about one instruction of any kind per four cycles),
+// so the inner pieces are written for instruction count: packed 16-bit prefix sums, counted key prefixes instead of
+// per-key branches, buffer addressing with wave-uniform bases.
 // ------------------------------------------------------------------------------------------------
 #define TT_LS 34       // dwords per lane column (68 uint16 levels; stride 34 keeps 8-byte alignment, conflict-free b64)
 #define TT_BW 64       // bins per band
 #define TT_MARGIN 6    // re-centre when the day's quantile bins come this close to a band edge
 #define TT_STEP 56     // band shift when answering stragglers (8 bins of overlap)
+#define TT_NPF 2       // chunk-0s of a bucket prefetched across the barrier (the other lists are loaded at use)
 
+template <int NPERT>
 struct TailBucket {
-    uint4 c0;       // first chunk (8 largest keys)
-    unsigned aux;   // count | overflow flag
-    int d;          // dayofyear index 0..365
+    uint4 c0[NPERT < TT_NPF ? NPERT : TT_NPF];
+    unsigned aux;  // count | overflow flag
+    int d;         // dayofyear index 0..365
 };
 
-template <int P, int TC, int NT, int K, int TR_ = NT / TC>
+template <int P, int TC, int NT, int NPERT, int TR_ = NT / TC>
 __global__ void __launch_bounds__(NT, NT == 256 ? 4 : (NT == 512 ? 2 : 1))
-k_thr_tails(const uint4* __restrict__ tails, const unsigned short* __restrict__ aux, const float* __restrict__ anom,
-            const int* __restrict__ doy_rows, const float* __restrict__ edges, long C, int ny, int nx, int row0, int row1,
-            int tiles_x, int Dd, const int* __restrict__ doy_start, const float* __restrict__ centres, int nb, double q, int wd,
-            float lower_bound, float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats,
+k_thr_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ aux, int NPER, const float* __restrict__ anom,
+            long C, int ny, int nx, int row0, int row1, int tiles_x, int Dd, const float* __restrict__ centres, int nb, double q,
+            int wd, float lower_bound, float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats,
             unsigned long long* __restrict__ dbg) {
     constexpr int TR = TR_;
     constexpr int NCELL = TR * TC;
-    constexpr int KC = K / 8;
+    constexpr int NPF = NPERT < TT_NPF ? NPERT : TT_NPF;
     static_assert(NCELL <= NT && NT - NCELL < 64, "tile does not match the thread count");
     constexpr int OR = TR - 2 * P, OC = TC - 2 * P;
     __shared__ unsigned lev[NT * TT_LS];
@@ -196,111 +258,104 @@ k_thr_tails(const uint4* __restrict__ tails, const unsigned short* __restrict__ 
     uint2* mycol2 = reinterpret_cast<uint2*>(mycol);
     typedef __attribute__((address_space(3))) unsigned lds_u32;
     const unsigned col_lds = (unsigned)(size_t)(lds_u32*)mycol;
-    const float inv_width = (float)(nb - 1) / (edges[nb] - edges[1]);
     const int base_max = nb - TT_BW > 0 ? nb - TT_BW : 0;
     auto clamp_base = [&](int b) { return b < 0 ? 0 : (b > base_max ? base_max : b); };
     int B0 = 0;
-    int BW = nb < TT_BW ? nb : TT_BW;  // levels 1..BW are bins B0 .. B0+BW-1
+    int BW = nb < TT_BW ? nb : TT_BW;      // levels 1..BW are bins B0 .. B0+BW-1
     constexpr int NLP = (TT_BW + 2 + 1) / 2;  // dwords holding levels 0 .. BW+1
+    const unsigned voff = (unsigned)cell * 16u;               // lane byte offset inside one chunk row of C cells
+    const unsigned chunk_row = (unsigned)C * 16u;              // bytes of one chunk row (C cells)
+    const size_t day_stride = (size_t)NPER * 2 * (size_t)C;   // uint4 elements per dayofyear
 
     auto load_bucket = [&](int d0) {
-        TailBucket b;
+        TailBucket<NPERT> b;
         b.d = d0;
-        b.c0 = tails[((size_t)d0 * KC) * C + cell];
+        const tl_rsrc_t r = tl_make_rsrc(lists + (size_t)d0 * day_stride);
+#pragma unroll
+        for (int p = 0; p < NPF; ++p) b.c0[p] = (p < NPER) ? tl_load_chunk(r, voff, (unsigned)(2 * p) * chunk_row) : make_uint4(0, 0, 0, 0);
         b.aux = aux[(size_t)d0 * C + cell];
         return b;
     };
     // +-1 on level k >= 1 of the lane's packed column
     auto bump = [&](int k, int sgn) {
-        const int odd = k & 1, even = k & ~1;
+        const int odd = k & 1;
         unsigned addr;
-        asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(addr) : "v"(even), "v"(col_lds));
-        const int v = sgn > 0 ? (odd ? 65536 : 1) : (odd ? -65536 : -1);
+        asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(addr) : "v"(k - odd), "v"(col_lds));
+        int v;
+        const int mul = sgn > 0 ? 65535 : -65535, one = sgn > 0 ? 1 : -1;
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(v) : "v"(odd), "v"(mul), "v"(one));
         __hip_atomic_fetch_add((lds_u32*)(size_t)addr, (unsigned)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     int mytot = 0;  // valid samples in this lane's window
-    unsigned long long n_slow = 0;
-    // add (sgn > 0) or remove one bucket
-    auto apply_bucket = [&](const TailBucket& b, int sgn) {
-        const int cnt = cell_valid ? (int)(b.aux & 0x3FFu) : 0;
-        int n_in = 0;
-        uint4 ch = b.c0;
-        bool more = cell_valid && cnt > 0;
-        bool exhausted = false;
-        unsigned lastkey = 0;
-        for (int jj = 0;; ++jj) {
-            const unsigned w[4] = {ch.x, ch.y, ch.z, ch.w};
-            bool go = more;
+    // the first n keys of a chunk (n <= 8, all inside the band) into the column
+    auto bump_chunk = [&](const uint4& ch, int n, int sgn, int nfix) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const unsigned key = (w[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu;
-                int lvl = (int)(key >> TAIL_POS_BITS) - B0;  // bin + 1 - B0; an empty key gives <= 0
+        for (int u = 0; u < 8; ++u) {
+            const bool on = n > u;
+            if (u >= nfix && __builtin_amdgcn_ballot_w64(on) == 0) break;
+            if (on) {
+                int lvl = tl_bin1(ch, u) - B0;
                 lvl = lvl > BW + 1 ? BW + 1 : lvl;
-                const bool in = go && lvl >= 1;
-                if (__builtin_amdgcn_ballot_w64(in) == 0) {  // sorted: nothing further down is inside the band
-                    go = false;
-                    break;
-                }
-                if (in) {
-                    bump(lvl, sgn);
-                    ++n_in;
-                }
-                go = in;
-                lastkey = key;
+                bump(lvl, sgn);
             }
-            // `go`: this lane's 8th key was still inside the band
-            const bool cont = go && jj + 1 < KC;
-            if (go && jj + 1 >= KC) exhausted = true;
-            if (__builtin_amdgcn_ballot_w64(cont) == 0) break;
-            if (cont) ch = tails[((size_t)b.d * KC + jj + 1) * C + cell];
-            more = cont;
         }
-        // the tail ended inside the band and the bucket holds more samples than keys: the rest from the anomalies
-        const bool slow = exhausted && cnt > K;
-        if (__builtin_amdgcn_ballot_w64(slow) != 0) {
-            const int s0 = doy_start[b.d], nd = doy_start[b.d + 1] - s0;
-            for (int pos = 0; pos < nd; ++pos) {
-                if (slow) {
-                    const float v = anom[(size_t)doy_rows[s0 + pos] * C + cell];
-                    const int bin = digitize_bin(v, edges, nb, inv_width);
-                    const unsigned key = bin < nb ? tail_key(bin, pos) : 0u;
-                    if (key != 0u && key < lastkey) {
-                        int lvl = bin + 1 - B0;
-                        lvl = lvl > BW + 1 ? BW + 1 : lvl;
-                        if (lvl >= 1) {
-                            bump(lvl, sgn);
-                            ++n_in;
-                        }
-                    }
+    };
+    // add (sgn > 0) or remove one bucket
+    auto apply_bucket = [&](const TailBucket<NPERT>& b, int sgn) {
+        const int cnt = cell_valid ? (int)(b.aux & 0x3FFu) : 0;
+        // in the band <=> bin >= B0 <=> key >= (B0 + 1) << 7 <=> key > lim
+        const unsigned lim = ((unsigned)(B0 + 1) << TAIL_POS_BITS) - 1u;
+        const unsigned lim_rep = lim | (lim << 16);
+        const tl_rsrc_t r = tl_make_rsrc(lists + (size_t)b.d * day_stride);
+        int n_in = 0;
+        uint4 extra[NPERT > NPF ? NPERT - NPF : 1];
+#pragma unroll
+        for (int p = NPF; p < NPERT; ++p)
+            extra[p - NPF] = (p < NPER) ? tl_load_chunk(r, voff, (unsigned)(2 * p) * chunk_row) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < NPERT; ++p) {
+            if (p < NPER) {  // uniform
+                const uint4 ch = p < NPF ? b.c0[p] : extra[p < NPF ? 0 : p - NPF];
+                const int n = cnt > 0 ? tl_count_above(ch, lim_rep) : 0;
+                n_in += n;
+                bump_chunk(ch, n, sgn, NPERT >= 3 ? 1 : 0);
+                if (__builtin_amdgcn_ballot_w64(n == 8) != 0) {  // the whole first chunk is inside the band: the second one too?
+                    const uint4 c1 = tl_load_chunk(r, voff, (unsigned)(2 * p + 1) * chunk_row);
+                    const int n1 = n == 8 ? tl_count_above(c1, lim_rep) : 0;
+                    n_in += n1;
+                    bump_chunk(c1, n1, sgn, 0);
                 }
             }
-            if (slow) ++n_slow;
         }
         const int below = cnt - n_in;  // everything under the band
         if (below > 0) __hip_atomic_fetch_add((lds_u32*)(size_t)col_lds, (unsigned)(sgn > 0 ? below : -below), __ATOMIC_RELAXED,
                                               __HIP_MEMORY_SCOPE_WORKGROUP);
         mytot += sgn > 0 ? cnt : -cnt;
     };
+    // in-place inclusive prefix sum over the lane's column, packed: (a0, a1) -> (a0, a0 + a1) + running total in both halves
     auto prefix = [&]() -> unsigned {
-        unsigned run = 0;
-#pragma unroll 4
+        unsigned run_rep = 0;
+#pragma unroll
         for (int i = 0; i < (NLP + 1) / 2; ++i) {
-            const uint2 w = mycol2[i];
-            const unsigned a0 = (w.x & 0xFFFFu) + run, a1 = (w.x >> 16) + a0;
-            const unsigned a2 = (w.y & 0xFFFFu) + a1, a3 = (w.y >> 16) + a2;
-            run = a3;
-            mycol2[i] = make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
+            uint2 w = mycol2[i];
+            w.x = pk_add_u16(w.x + (w.x << 16), run_rep);
+            run_rep = __builtin_amdgcn_perm(w.x, w.x, 0x03020302u);
+            w.y = pk_add_u16(w.y + (w.y << 16), run_rep);
+            run_rep = __builtin_amdgcn_perm(w.y, w.y, 0x03020302u);
+            mycol2[i] = w;
         }
-        return run;
+        return run_rep & 0xFFFFu;
     };
     auto unprefix = [&]() {
         unsigned prev = 0;
-#pragma unroll 4
+#pragma unroll
         for (int i = 0; i < (NLP + 1) / 2; ++i) {
             const uint2 w = mycol2[i];
-            const unsigned a0 = w.x & 0xFFFFu, a1 = w.x >> 16, a2 = w.y & 0xFFFFu, a3 = w.y >> 16;
-            mycol2[i] = make_uint2((a0 - prev) | ((a1 - a0) << 16), (a2 - a1) | ((a3 - a2) << 16));
-            prev = a3;
+            uint2 o;
+            o.x = pk_sub_u16(w.x, __builtin_amdgcn_alignbit(w.x, prev, 16));  // (c0 - prev_hi, c1 - c0)
+            o.y = pk_sub_u16(w.y, __builtin_amdgcn_alignbit(w.y, w.x, 16));
+            prev = w.y;
+            mycol2[i] = o;
         }
     };
     auto wrap = [&](int d) { return ((d % NDOY) + NDOY) % NDOY; };
@@ -308,9 +363,9 @@ k_thr_tails(const uint4* __restrict__ tails, const unsigned short* __restrict__ 
     auto rebuild = [&](int d) {
         for (int r = 0; r < TT_LS / 2; ++r) mycol2[r] = make_uint2(0u, 0u);
         mytot = 0;
-        TailBucket cur = load_bucket(wrap(d - pd));
+        TailBucket<NPERT> cur = load_bucket(wrap(d - pd));
         for (int o = -pd + 1; o <= pd; ++o) {
-            const TailBucket nxt = load_bucket(wrap(d + o));
+            const TailBucket<NPERT> nxt = load_bucket(wrap(d + o));
             apply_bucket(cur, +1);
             cur = nxt;
         }
@@ -423,9 +478,9 @@ k_thr_tails(const uint4* __restrict__ tails, const unsigned short* __restrict__ 
         thr[(size_t)d * C + cell] = t32;
     };
 
-    // ---- first band of the block: every cell's own bucket of the first day gives an estimate of its quantile bin
-    // (the key of rank ceil((1 - q) n) among its n samples); the band is centred on the tile's range of estimates.
-    // A bad estimate only costs passes below, never a wrong result.
+    // ---- first band of the block: every cell's own bucket of the first day gives an estimate of its quantile bin (the
+    // largest of the keys of rank ceil((1 - q) n / lists) in its lists); the band is centred on the tile's range of
+    // estimates.  A bad estimate only costs passes below, never a wrong result.
     if (t == 0) {
         s_est_min = 0x7fffffff;
         s_est_max = -1;
@@ -435,16 +490,15 @@ k_thr_tails(const uint4* __restrict__ tails, const unsigned short* __restrict__ 
     }
     __syncthreads();
     {
-        const TailBucket b = load_bucket(d_begin);
+        const TailBucket<NPERT> b = load_bucket(d_begin);
         const int cnt = cell_valid ? (int)(b.aux & 0x3FFu) : 0;
         if (cnt > 0) {
-            int rank = (int)ceil((1.0 - q) * (double)cnt);
+            int rank = (int)ceil((1.0 - q) * (double)cnt / (double)NPER);
             rank = rank < 1 ? 1 : (rank > 8 ? 8 : rank);
-            const unsigned w[4] = {b.c0.x, b.c0.y, b.c0.z, b.c0.w};
             unsigned key = 0;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (u == rank - 1) key = (w[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu;
+                if (u == rank - 1) key = tl_key(b.c0[0], u);
             if (key != 0u) {
                 const int est = (int)(key >> TAIL_POS_BITS) - 1;
                 atomicMin(&s_est_min, est);
@@ -465,13 +519,21 @@ k_thr_tails(const uint4* __restrict__ tails, const unsigned short* __restrict__ 
     int hint = -1;
     bool need_rebuild = true;
     unsigned long long n_rebuild = 0, n_pass = 0;
-    TailBucket pin, pout;
+    TailBucket<NPERT> pin, pout;
     pin.d = pout.d = 0;
     pin.aux = pout.aux = 0;
-    pin.c0 = pout.c0 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < NPF; ++p) pin.c0[p] = pout.c0[p] = make_uint4(0, 0, 0, 0);
+#ifdef MAREX_STAMPS
+    unsigned long long st_p1 = 0, st_p2 = 0, st_bar = 0;
+#define STAMP() __builtin_amdgcn_s_memtime()
+#endif
     for (int dd = 0; dd < ndays; ++dd) {
         const int d = d_begin + dd;
         const int dpar = dd & 1;
+#ifdef MAREX_STAMPS
+        const unsigned long long tA = STAMP();
+#endif
         // ---------------- P1: this lane's column for day d
         if (need_rebuild) {
             rebuild(d);
@@ -488,13 +550,24 @@ k_thr_tails(const uint4* __restrict__ tails, const unsigned short* __restrict__ 
             pin = load_bucket(wrap(d + 1 + pd));
             pout = load_bucket(wrap(d - pd));
         }
+#ifdef MAREX_STAMPS
+        const unsigned long long tB = STAMP();
+        st_p1 += tB - tA;
+#endif
         // ---------------- P2: quantile level of every output cell; stragglers move the band
         bool resolved = !(is_out && !land);
         int tried_lo = B0, tried_hi = B0;
         bool excursion = false;
         for (int pass = 0;; ++pass) {
             const int par = pass & 1;
+#ifdef MAREX_STAMPS
+            const unsigned long long tC0 = STAMP();
+#endif
             __syncthreads();
+#ifdef MAREX_STAMPS
+            const unsigned long long tC = STAMP();
+            st_bar += tC - tC0;
+#endif
             if (t == 0) {
                 s_lo[par ^ 1] = 0;
                 s_hi[par ^ 1] = 0;
@@ -537,7 +610,14 @@ k_thr_tails(const uint4* __restrict__ tails, const unsigned short* __restrict__ 
                     resolved = true;
                 }
             }
+#ifdef MAREX_STAMPS
+            const unsigned long long tD = STAMP();
+            st_p2 += tD - tC;
+#endif
             __syncthreads();
+#ifdef MAREX_STAMPS
+            st_bar += STAMP() - tD;
+#endif
             const int lo = s_lo[par], hi = s_hi[par];
             if (!lo && !hi) break;
             // stragglers: a band further down (first) or further up than anything tried for this day
@@ -567,8 +647,6 @@ k_thr_tails(const uint4* __restrict__ tails, const unsigned short* __restrict__ 
                         B0 = want;
                         BW = nb - B0 < TT_BW ? nb - B0 : TT_BW;
                         need_rebuild = true;
-                    } else if (excursion) {
-                        need_rebuild = false;  // the last pass already sits on the wanted band
                     }
                 }
             }
@@ -581,15 +659,20 @@ k_thr_tails(const uint4* __restrict__ tails, const unsigned short* __restrict__ 
         kmax = b > kmax ? b : kmax;
         nlow += __shfl_down(nlow, sft, 64);
         nhigh += __shfl_down(nhigh, sft, 64);
-        n_slow += __shfl_down(n_slow, sft, 64);
     }
     if ((t & 63) == 0) {
         if (kmin != 0xFFFFFFFFu) atomicMin(&stats->min_key, kmin);
         if (kmax != 0u) atomicMax(&stats->max_key, kmax);
         if (nlow) atomicAdd(&stats->n_too_low, nlow);
         if (nhigh) atomicAdd(&stats->n_too_high, nhigh);
-        if (dbg && n_slow) atomicAdd(&dbg[1], n_slow);
     }
+#ifdef MAREX_STAMPS
+    if (dbg && t == 0) {
+        atomicAdd(&dbg[5], st_p1);
+        atomicAdd(&dbg[6], st_p2);
+        atomicAdd(&dbg[7], st_bar);
+    }
+#endif
     if (dbg && t == 0) {
         atomicAdd(&dbg[0], n_rebuild);
         atomicAdd(&dbg[2], n_pass);
@@ -597,19 +680,17 @@ k_thr_tails(const uint4* __restrict__ tails, const unsigned short* __restrict__ 
     }
 }
 
-extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* tails, const uint16_t* aux, int K, const float* anom,
-                                                 int64_t T_out, int64_t C, int ny, int nx, const int32_t* doy_start,
-                                                 const int32_t* doy_rows, int max_bucket, const float* edges, const float* centres,
+extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, const float* anom,
+                                                 int64_t T_out, int64_t C, int ny, int nx, int max_bucket, const float* centres,
                                                  int nb, double q, int wd, int ws, float lower_bound, float upper_bound, int row0,
                                                  int row1, float* thr_doy_major, marex_thr_stats* stats) {
     if (!ctx) return -1;
-    if (!tails || !aux || !anom || !doy_start || !doy_rows || !edges || !centres || !thr_doy_major || !stats || T_out <= 0 || C <= 0)
+    if (!lists || !aux || !anom || !centres || !thr_doy_major || !stats || T_out <= 0 || C <= 0)
         return fail(ctx, -1, "marex_hobday_thresholds_tails_f32: null pointer or empty shape");
     if (wd < 3 || wd > 365 || (wd & 1) == 0)
         return fail(ctx, -1, "marex_hobday_thresholds_tails_f32: window_days_hobday must be odd and in 3..365");
     if (ws < 1 || (ws & 1) == 0) return fail(ctx, -1, "marex_hobday_thresholds_tails_f32: window_spatial_hobday must be odd");
     if (!(q > 0.0 && q <= 1.0)) return fail(ctx, -1, "marex_hobday_thresholds_tails_f32: q must be in (0, 1]");
-    if (K != 16 && K != 32) return fail(ctx, -1, "marex_hobday_thresholds_tails_f32: K must be 16 or 32");
     if (ny == 0) {
         if (ws > 1) return fail(ctx, -1, "marex_hobday_thresholds_tails_f32: spatial pooling needs a structured grid");
         nx = (int)C;
@@ -622,10 +703,11 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* tai
     }
     const int p = ws / 2;
     if (nb < 4 || nb > TAIL_MAX_NB || max_bucket < 1 || max_bucket > TAIL_MAX_BUCKET || p > 3 ||
-        (int64_t)max_bucket * wd * ws * ws > 65535)
+        (int64_t)max_bucket * wd * ws * ws > 65535 || C * 16 > 0xFFFFFFFFll / 16)
         return fail(ctx, -4, "marex_hobday_thresholds_tails_f32: shape outside the tail kernel (nb <= %d, buckets <= %d rows, "
                              "ws <= 7, pooled window <= 65535 samples)", TAIL_MAX_NB, TAIL_MAX_BUCKET);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int NPER = tails_nper(max_bucket);
     const int tile_pref = ctx_opt(ctx, "THR_TILE", (ny > 0 && p > 0 && max_bucket >= 24) ? 32 : 16);
     const bool big = (ny > 0 && p > 0) && tile_pref == 32 && (row1 - row0) >= 16 && nx >= 16;
     const int NT = big ? 1024 : 256;
@@ -654,14 +736,18 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* tai
     }
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((NDOY + Dd - 1) / Dd));
     unsigned long long* dbg = ctx_debug_counters(ctx);
-    const uint4* tl = reinterpret_cast<const uint4*>(tails);
-#define MAREX_TT_ARGS tl, aux, anom, doy_rows, edges, (long)C, ny, nx, row0, row1, tiles_x, Dd, doy_start, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats, dbg
-#define MAREX_TT_LAUNCH(PP, TCC, NTT, ...)                                                                                         \
-    do {                                                                                                                           \
-        if (K == 16)                                                                                                               \
-            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 16, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);    \
-        else                                                                                                                       \
-            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 32, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);    \
+    const uint4* tl = reinterpret_cast<const uint4*>(lists);
+#define MAREX_TT_ARGS tl, aux, NPER, anom, (long)C, ny, nx, row0, row1, tiles_x, Dd, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats, dbg
+#define MAREX_TT_LAUNCH(PP, TCC, NTT, ...)                                                                                           \
+    do {                                                                                                                             \
+        if (NPER <= 1)                                                                                                               \
+            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 1, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
+        else if (NPER <= 3)                                                                                                          \
+            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 3, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
+        else if (NPER <= 6)                                                                                                          \
+            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 6, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 8, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
     } while (0)
     {
         LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
@@ -690,19 +776,17 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* tai
 
 // ------------------------------------------------------------------------------------------------
 // K_M from tails: extreme[t, c] = anom[t, c] >= thr[doy(t), c]  (detect.py:2003-2004) without reading the anomalies.
-// Every sample at or above the threshold sits at the top of its bucket's tail: keys whose bin lies above the bin of
-// the threshold are extremes, keys in the threshold's own bin are compared as numbers (a handful per wave and day),
-// the first key below ends the walk.  Buckets whose tail does not reach below the threshold, and buckets holding
-// values beyond the edge table, are decided on the anomalies themselves (float4 rows, like the plain mask kernel).
+// Every sample at or above the threshold sits at the top of one of its bucket's lists: keys whose bin lies above the bin
+// of the threshold are extremes, keys in the threshold's own bin are compared as numbers (a handful per wave and day),
+// the first key below ends the walk of a list.  Buckets holding values beyond the edge table (aux bit 15) are decided on
+// the anomalies themselves (float4 rows, like the plain mask kernel).
 // Lane = 4 consecutive cells: 16-byte key chunks of 4 cells are one contiguous 64-byte run, mask stores are 4 bytes.
 // ------------------------------------------------------------------------------------------------
-template <int K>
 __global__ void __launch_bounds__(256)
-k_mask_tails(const uint4* __restrict__ tails, const unsigned short* __restrict__ aux, const float* __restrict__ anom,
+k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ aux, int NPER, const float* __restrict__ anom,
              const float* __restrict__ edges, int nb, const float* __restrict__ thr, const int* __restrict__ doy_start,
              const int* __restrict__ doy_rows, long C, long c0, long c1, unsigned char* __restrict__ out,
              unsigned long long* __restrict__ n_true, unsigned long long* __restrict__ dbg) {
-    constexpr int KC = K / 8;
     const int nchunk = (int)gridDim.y;
     const int dA = (int)blockIdx.y * NDOY / nchunk, dB = ((int)blockIdx.y + 1) * NDOY / nchunk;
     const long c = c0 + ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -719,45 +803,58 @@ k_mask_tails(const uint4* __restrict__ tails, const unsigned short* __restrict__
             const unsigned av[4] = {ax.x & 0xFFFFu, ax.x >> 16, ax.y & 0xFFFFu, ax.y >> 16};
             unsigned bits[4][4];
             int kt[4];
-            bool slow = false, open[4];
+            bool slow = false, walk[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 bits[i][0] = bits[i][1] = bits[i][2] = bits[i][3] = 0u;
                 const bool isnum = tv[i] == tv[i];
                 kt[i] = isnum ? digitize_bin(tv[i], edges, nb, inv_width) : 0x7fff;  // NaN threshold: nothing is extreme
                 slow = slow || (isnum && (av[i] & 0x8000u));                            // values beyond the table: look at them
-                open[i] = isnum && (av[i] & 0x3FFu) > 0;                                // still walking this cell's tail
+                walk[i] = isnum && (av[i] & 0x3FFu) > 0;
             }
-            for (int jj = 0; jj < KC; ++jj) {
-                bool any_open = false;
+            // one chunk of one cell: keys at or above the threshold's bin set their row's bit; returns "all 8 were"
+            auto scan = [&](const uint4& ch, int i) -> bool {
+                bool on = walk[i];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) any_open = any_open || open[i];
-                if (__builtin_amdgcn_ballot_w64(any_open && !slow) == 0) break;
-                uint4 ch[4];
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned key = tl_key(ch, u);
+                    const int bin = (int)(key >> TAIL_POS_BITS) - 1;  // -1 for an empty key
+                    const int pos = (int)(key & (TAIL_MAX_BUCKET - 1));
+                    on = on && bin >= kt[i];  // sorted: nothing further down reaches the threshold
+                    if (on) {
+                        bool ext = bin > kt[i];
+                        if (!ext) ext = anom[(size_t)doy_rows[r0 + pos] * C + c + i] >= tv[i];  // the threshold's own bin
+                        if (ext) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ch[i] = tails[((size_t)d * KC + jj) * C + c + i];
+                            for (int wi = 0; wi < 4; ++wi)
+                                if ((pos >> 5) == wi) bits[i][wi] |= 1u << (pos & 31);
+                        }
+                    }
+                }
+                return on;
+            };
+            if (__builtin_amdgcn_ballot_w64(!slow) != 0) {
+                for (int p = 0; p < NPER; ++p) {
+                    const uint4* row = lists + (((size_t)d * NPER + p) * 2) * C + c;
+                    uint4 ch[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned w[4] = {ch[i].x, ch[i].y, ch[i].z, ch[i].w};
+                    for (int i = 0; i < 4; ++i) ch[i] = row[i];
+                    bool more[4];
+                    bool any_more = false;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const unsigned key = (w[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu;
-                        const int bin = (int)(key >> TAIL_POS_BITS) - 1;  // -1 for an empty key
-                        const int pos = (int)(key & (TAIL_MAX_BUCKET - 1));
-                        if (open[i]) {
-                            bool ext = bin > kt[i];
-                            if (bin == kt[i])  // the threshold's own bin: compare the numbers
-                                ext = anom[(size_t)doy_rows[r0 + pos] * C + c + i] >= tv[i];
-                            if (bin < kt[i]) open[i] = false;  // sorted: nothing further down reaches the threshold
-                            if (ext) {
+                    for (int i = 0; i < 4; ++i) {
+                        more[i] = slow ? false : scan(ch[i], i);
+                        any_more = any_more || more[i];
+                    }
+                    if (__builtin_amdgcn_ballot_w64(any_more) != 0) {  // a first chunk entirely at or above the threshold
 #pragma unroll
-                                for (int wi = 0; wi < 4; ++wi)
-                                    if ((pos >> 5) == wi) bits[i][wi] |= 1u << (pos & 31);
+                        for (int i = 0; i < 4; ++i) {
+                            if (more[i]) {
+                                const uint4 c1v = row[(size_t)C + i];
+                                scan(c1v, i);
                             }
                         }
                     }
-                    // tail used up while still at or above the threshold's bin, and the bucket holds more samples than keys
-                    if (open[i] && jj == KC - 1 && (int)(av[i] & 0x3FFu) > K) slow = true;
                 }
             }
             if (slow) {
@@ -796,15 +893,15 @@ k_mask_tails(const uint4* __restrict__ tails, const unsigned short* __restrict__
     }
 }
 
-extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* tails, const uint16_t* aux, int K, const float* anom,
+extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, int max_bucket, const float* anom,
                                            const float* edges, int nb, const float* thr_doy_major, const int32_t* doy_start,
                                            const int32_t* doy_rows, int64_t T_out, int64_t C, int64_t c0, int64_t c1,
                                            uint8_t* extreme, unsigned long long* n_true) {
     if (!ctx) return -1;
-    if (!tails || !aux || !anom || !edges || !thr_doy_major || !doy_start || !doy_rows || !extreme || T_out <= 0 || C <= 0 || nb < 4)
+    if (!lists || !aux || !anom || !edges || !thr_doy_major || !doy_start || !doy_rows || !extreme || T_out <= 0 || C <= 0 || nb < 4)
         return fail(ctx, -1, "marex_mask_ge_doy_tails_f32: null pointer or empty shape");
     if (c0 < 0 || c1 > C || c0 >= c1) return fail(ctx, -1, "marex_mask_ge_doy_tails_f32: need 0 <= c0 < c1 <= C");
-    if (K != 16 && K != 32) return fail(ctx, -1, "marex_mask_ge_doy_tails_f32: K must be 16 or 32");
+    if (max_bucket < 1 || max_bucket > TAIL_MAX_BUCKET) return fail(ctx, -4, "marex_mask_ge_doy_tails_f32: buckets must hold 1..%d rows", TAIL_MAX_BUCKET);
     const bool vec = (C % 4 == 0) && (c0 % 4 == 0) && (c1 % 4 == 0) && (((uintptr_t)anom | (uintptr_t)thr_doy_major) % 16 == 0) &&
                      ((uintptr_t)extreme % 4 == 0) && ((uintptr_t)aux % 8 == 0) && nb < 0x7fff;
     if (!vec)  // shapes the 4-cell kernel does not cover: the plain compare on the anomalies
@@ -816,13 +913,9 @@ extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* tails, co
         unsigned chunks = (4096 + ncb - 1) / ncb;
         chunks = chunks < MASK_DOY_CHUNKS ? MASK_DOY_CHUNKS : (chunks > 61 ? 61 : chunks);
         unsigned long long* dbg = ctx_debug_counters(ctx);
-        const uint4* tl = reinterpret_cast<const uint4*>(tails);
-        if (K == 16)
-            hipLaunchKernelGGL(k_mask_tails<16>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, tl, aux, anom, edges, nb, thr_doy_major,
-                               doy_start, doy_rows, (long)C, (long)c0, (long)c1, extreme, n_true, dbg);
-        else
-            hipLaunchKernelGGL(k_mask_tails<32>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, tl, aux, anom, edges, nb, thr_doy_major,
-                               doy_start, doy_rows, (long)C, (long)c0, (long)c1, extreme, n_true, dbg);
+        hipLaunchKernelGGL(k_mask_tails, dim3(ncb, chunks), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4*>(lists), aux,
+                           tails_nper(max_bucket), anom, edges, nb, thr_doy_major, doy_start, doy_rows, (long)C, (long)c0, (long)c1,
+                           extreme, n_true, dbg);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;

@@ -1,25 +1,27 @@
 #pragma once
-// marex_tails.hip.h -- "tails": the upper end of every (cell, dayofyear) histogram as a short sorted list.
+// marex_tails.hip.h -- "tails": every (cell, dayofyear) histogram as short SORTED lists of its samples.
 //
 // The reference counts every anomaly into a dense (dayofyear, bin) histogram per cell and only ever asks it for one
-// high quantile (detect.py:2638-2648, 2465-2559).  For q >= 0.6 the answer is decided by the few largest samples of the
-// dayofyear buckets in the pooled window; everything below only has to be COUNTED.  A tail is that upper end:
+// high quantile (detect.py:2638-2648, 2465-2559).  For q >= 0.6 the answer is decided by the largest samples of the
+// dayofyear buckets in the pooled window; everything below only has to be COUNTED.  The device therefore keeps the
+// samples of a bucket as 16-bit keys in lists that are sorted descending, so that a consumer reads the top of each list
+// and stops at the first key it does not need:
 //
-//   key   = ((bin + 1) << 7) | pos      16 bits; bin = np.digitize(anom, edges) - 1 (< nb <= 511), pos = position of the
-//                                       sample inside its dayofyear bucket (rows doy_start[d] + pos, < 128); 0 = empty
-//   tails[d][j][c] (uint4 = 8 keys)     chunk j of the K keys of bucket (dayofyear d + 1, cell c), the K LARGEST keys of
-//                                       the bucket sorted descending (chunk-major: one 16-byte load per lane and chunk,
-//                                       contiguous across consecutive cells)
-//   aux[d][c] (uint16)                  bits 0..9: samples of the bucket with a valid bin (bin < nb, the ones the
-//                                       reference's histogram counts); bit 15: the bucket holds a non-NaN value at or
-//                                       beyond the last edge (only the mask has to look at it)
+//   key   = ((bin + 1) << 7) | pos      bin = np.digitize(anom, edges) - 1 (< nb <= 511), pos = position of the sample
+//                                       inside its dayofyear bucket (output row doy_rows[doy_start[d] + pos], < 128);
+//                                       0 = empty slot.  Samples the reference's histogram drops (NaN, >= edges[nb])
+//                                       have no key.
+//   lists[d][p][j][c] (uint4 = 8 keys)  chunk j (0: the 8 largest, 1: the rest) of list p of bucket (dayofyear d + 1,
+//                                       cell c).  A bucket's keys are PARTITIONED over its NPER = ceil(max_bucket / 16)
+//                                       lists of <= 16 keys, each sorted descending; which keys share a list is the
+//                                       producer's business (the anomaly kernel: 16 consecutive years; the extraction
+//                                       kernel: 16 consecutive rows).  Chunk-major: one 16-byte load per lane, contiguous
+//                                       across consecutive cells; consumers rarely touch chunk 1.
+//   aux[d][c] (uint16)                  bits 0..9: number of keys of the bucket (= the samples the reference counts);
+//                                       bit 15: the bucket holds a non-NaN value >= edges[nb] (only the mask cares)
 //
-// Keys are unique inside a bucket (pos), so "the samples that are not in the tail" are exactly those with a key below
-// the K-th one: a consumer that needs them (tail exhausted while still inside its band of levels) re-reads the
-// bucket's anomalies and takes the keys below the last tail key -- no flags, no second data structure.
-//
-// The sorting networks below work on PACKED PAIRS: one 32-bit register holds the keys of two independent buckets
-// (two neighbouring dayofyears of one cell), v_pk_max_u16 / v_pk_min_u16 order both at once.
+// The sorting network works on PACKED PAIRS: one 32-bit register holds the keys of two independent buckets (two
+// neighbouring dayofyears of one cell), v_pk_max_u16 / v_pk_min_u16 order both at once.
 #include <stdint.h>
 
 #if defined(__HIPCC__) || defined(__CUDACC__)
@@ -31,6 +33,8 @@
 #define TAIL_POS_BITS 7
 #define TAIL_MAX_BUCKET 128  // pos < 2^7
 #define TAIL_MAX_NB 511      // bin + 1 < 2^9
+#define TAIL_LIST 16         // keys per list
+#define TAIL_MAX_NPER (TAIL_MAX_BUCKET / TAIL_LIST)
 
 typedef unsigned short marex_us2 __attribute__((ext_vector_type(2)));
 
@@ -47,7 +51,7 @@ MAREX_HD void pk_cx(unsigned& a, unsigned& b) {
     b = lo;
 }
 
-// v[0..N) bitonic (first descending then ascending, or any rotation-free bitonic sequence) -> sorted descending
+// v[0..N) bitonic -> sorted descending
 template <int N>
 MAREX_HD void bitonic_merge_desc(unsigned (&v)[N]) {
 #pragma unroll
@@ -63,7 +67,6 @@ template <int N>
 MAREX_HD void bitonic_sort_desc(unsigned (&v)[N]) {
 #pragma unroll
     for (int size = 2; size <= N; size <<= 1) {
-        // first step of every merge compares i with its mirror inside the block of `size` (makes the halves bitonic)
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int j = i ^ (size - 1);
@@ -78,33 +81,18 @@ MAREX_HD void bitonic_sort_desc(unsigned (&v)[N]) {
     }
 }
 
-// top[0..K) sorted descending, nw[0..B) sorted descending (B <= K, both powers of two or K a multiple of B):
-// top <- the K largest of the union, sorted descending.  nw is destroyed.
-template <int K, int B>
-MAREX_HD void tail_merge(unsigned (&top)[K], unsigned (&nw)[B]) {
-    static_assert(B <= K, "batch larger than the tail");
-    // the first K - B entries of top stay in the result whatever nw holds (at most B new keys can pass them); the last
-    // B compete with nw: a half-cleaner of two sorted runs leaves the B largest, as a bitonic sequence
-    unsigned cand[B];
-#pragma unroll
-    for (int i = 0; i < B; ++i) cand[i] = pk_max_u16(top[K - B + i], nw[B - 1 - i]);
-    bitonic_merge_desc<B>(cand);
-    if (K == B) {
-#pragma unroll
-        for (int i = 0; i < B; ++i) top[i] = cand[i];
-        return;
-    }
-    // K > B: merge the safe prefix (sorted) with cand (sorted): prefix ++ reverse(cand) is bitonic.  For K = 2B this is
-    // a plain bitonic merge; for larger K only the last 2B entries can change order beyond position K - 2B ... keep it
-    // simple and exact: merge everything (K is 16 or 32 here).
-    unsigned all[K];
-#pragma unroll
-    for (int i = 0; i < K - B; ++i) all[i] = top[i];
-#pragma unroll
-    for (int i = 0; i < B; ++i) all[K - B + i] = cand[B - 1 - i];
-    bitonic_merge_desc<K>(all);
-#pragma unroll
-    for (int i = 0; i < K; ++i) top[i] = all[i];
+// 16 keys, any order -> sorted descending: Batcher's odd-even merge sort, 63 compare-exchanges (the bitonic sorter needs
+// 80).  The list is generated and checked exhaustively (0-1 principle, all 2^16 inputs) by tests/test_tail_networks.py.
+MAREX_HD void sort16_desc(unsigned (&v)[16]) {
+#define CX(a, b) pk_cx(v[a], v[b])
+    CX(0, 1); CX(2, 3); CX(0, 2); CX(1, 3); CX(1, 2); CX(4, 5); CX(6, 7); CX(4, 6); CX(5, 7); CX(5, 6); CX(0, 4);
+    CX(2, 6); CX(2, 4); CX(1, 5); CX(3, 7); CX(3, 5); CX(1, 2); CX(3, 4); CX(5, 6); CX(8, 9); CX(10, 11); CX(8, 10);
+    CX(9, 11); CX(9, 10); CX(12, 13); CX(14, 15); CX(12, 14); CX(13, 15); CX(13, 14); CX(8, 12); CX(10, 14);
+    CX(10, 12); CX(9, 13); CX(11, 15); CX(11, 13); CX(9, 10); CX(11, 12); CX(13, 14); CX(0, 8); CX(4, 12); CX(4, 8);
+    CX(2, 10); CX(6, 14); CX(6, 10); CX(2, 4); CX(6, 8); CX(10, 12); CX(1, 9); CX(5, 13); CX(5, 9); CX(3, 11);
+    CX(7, 15); CX(7, 11); CX(3, 5); CX(7, 9); CX(11, 13); CX(1, 2); CX(3, 4); CX(5, 6); CX(7, 8); CX(9, 10);
+    CX(11, 12); CX(13, 14);
+#undef CX
 }
 
 MAREX_HD unsigned tail_key(int bin, int pos) { return ((unsigned)(bin + 1) << TAIL_POS_BITS) | (unsigned)pos; }

@@ -664,11 +664,14 @@ def preprocess_data(
     bins_for = None
     if need_bins is not None:
         def bins_for(dcal):
-            k = eng.tails_plan(dcal, need_bins, threshold_percentile / 100.0, int(window_days_hobday), int(ws_eff) if ws_eff else 1)
+            k = eng.tails_plan(dcal, need_bins, threshold_percentile / 100.0, int(window_days_hobday), int(ws_eff) if ws_eff else 1,
+                               int(fb_cells[0]))
             return need_bins if k is None else None
 
+    fb_cells = [0]
     for sh in blocks:
         fb = field if single else field.block(sh)
+        fb_cells[0] = fb.shape[1]
         rows = None if single or not field.gridded else (sh.own0 - sh.in0, sh.own1 - sh.in0)
         a = _anomaly_core(eng, fb, method_anomaly, window_year_baseline, smooth_days_baseline, detrend_orders,
                           force_zero_mean, reference_period, bins_for)

@@ -222,33 +222,31 @@ class HotPath:
         }
 
     # ------------------------------------------------------------------ stage a10/a11 on tails (default)
-    def tails_plan(self, dcal: DeviceCalendar, bins: BinTable, q: float, wd: int, ws: int) -> Optional[int]:
-        """Number of keys per (dayofyear, cell) tail (16 / 32) when the tail kernels take this configuration, else None
-        (bin-matrix kernels).  Results are identical on both paths; the rule only keeps the threshold kernel away from
-        tails that are too short for the quantile asked for (it would re-read most buckets from the anomalies)."""
+    def tails_plan(self, dcal: DeviceCalendar, bins: BinTable, q: float, wd: int, ws: int, C: Optional[int] = None) -> Optional[int]:
+        """Number of sorted lists per (dayofyear, cell) bucket when the tail kernels take this configuration, else None
+        (bin-matrix kernels).  Results are identical on both paths (include/marex_hip.h, TAILS)."""
         if self.hobday_path == "bins":
             return None
         nd = int(np.diff(dcal.plan.doy_start).max())
-        if not (bins.nb <= 511 and 1 <= nd <= 128 and ws <= 7 and nd * wd * ws * ws <= 65535):
+        if not (bins.nb <= 511 and 1 <= nd <= 128 and ws <= 7 and nd * wd * ws * ws <= 65535 and (C is None or C <= (1 << 24))):
             return None
-        K = 16 if nd <= 16 else 32
-        if self.hobday_path != "tails" and nd > K and nd * (1.0 - q) > K / 3.0:
-            return None
-        return K
+        return (nd + 15) // 16
 
-    def tail_extract(self, anom: torch.Tensor, dcal: DeviceCalendar, bins: BinTable, K: int, wsp: Optional[dict] = None):
-        """Sorted upper tails of every (dayofyear, cell) bucket of ``anom`` (include/marex_hip.h, TAILS)."""
+    def tail_extract(self, anom: torch.Tensor, dcal: DeviceCalendar, bins: BinTable, wsp: Optional[dict] = None):
+        """Sorted key lists of every (dayofyear, cell) bucket of ``anom`` (include/marex_hip.h, TAILS)."""
         self._bind_stream()
         T_out, Cn = anom.shape
         edges = self.bin_tables(bins)[0]
-        tails = self._buf(wsp, "tails", (N_DOY, K // 8, Cn, 8), torch.int16, self.device)
+        nd = int(np.diff(dcal.plan.doy_start).max())
+        nper = (nd + 15) // 16
+        lists = self._buf(wsp, "tails", (N_DOY, nper, 2, Cn, 8), torch.int16, self.device)
         aux = self._buf(wsp, "tails_aux", (N_DOY, Cn), torch.int16, self.device)
         rc = self.lib.marex_tail_extract_f32(
-            self.ctx.handle, anom.data_ptr(), T_out, Cn, dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(),
-            int(np.diff(dcal.plan.doy_start).max()), edges.data_ptr(), bins.nb, int(K), tails.data_ptr(), aux.data_ptr(),
+            self.ctx.handle, anom.data_ptr(), T_out, Cn, dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), nd,
+            edges.data_ptr(), bins.nb, lists.data_ptr(), aux.data_ptr(),
         )
         self.ctx.check(rc, "marex_tail_extract_f32")
-        return {"tails": tails, "aux": aux, "K": int(K), "_keep": edges}
+        return {"tails": lists, "aux": aux, "max_bucket": nd, "_keep": edges}
 
     def hobday_thresholds_tails(self, tl: dict, anom: torch.Tensor, dcal: DeviceCalendar, bins: BinTable, q: float, wd: int,
                                 ws: int, ny: int, nx: int, rows: Optional[tuple] = None, wsp: Optional[dict] = None):
@@ -259,15 +257,14 @@ class HotPath:
         stats = self._buf(wsp, "thr_stats", (4,), torch.int32, self.device)
         stats.zero_()
         stats[0:1].fill_(-1)
-        edges, centres = self.bin_tables(bins)
+        centres = self.bin_tables(bins)[1]
         rc = self.lib.marex_hobday_thresholds_tails_f32(
-            self.ctx.handle, tl["tails"].data_ptr(), tl["aux"].data_ptr(), int(tl["K"]), anom.data_ptr(), T_out, Cn, int(ny),
-            int(nx), dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), int(np.diff(dcal.plan.doy_start).max()),
-            edges.data_ptr(), centres.data_ptr(), bins.nb, float(q), int(wd), int(ws), float(bins.lower_bound),
+            self.ctx.handle, tl["tails"].data_ptr(), tl["aux"].data_ptr(), anom.data_ptr(), T_out, Cn, int(ny), int(nx),
+            int(tl["max_bucket"]), centres.data_ptr(), bins.nb, float(q), int(wd), int(ws), float(bins.lower_bound),
             float(bins.upper_bound), int(row0), int(row1), thr.data_ptr(), stats.data_ptr(),
         )
         self.ctx.check(rc, "marex_hobday_thresholds_tails_f32")
-        return {"thr_doy_major": thr, "stats_dev": stats, "_keep": (edges, centres)}
+        return {"thr_doy_major": thr, "stats_dev": stats, "_keep": centres}
 
     def mask_ge_doy_tails(self, tl: dict, anom: torch.Tensor, thr_doy_major: torch.Tensor, dcal: DeviceCalendar,
                           bins: BinTable, cells: Optional[tuple] = None, wsp: Optional[dict] = None):
@@ -279,7 +276,7 @@ class HotPath:
         n_true.zero_()
         edges = self.bin_tables(bins)[0]
         rc = self.lib.marex_mask_ge_doy_tails_f32(
-            self.ctx.handle, tl["tails"].data_ptr(), tl["aux"].data_ptr(), int(tl["K"]), anom.data_ptr(), edges.data_ptr(),
+            self.ctx.handle, tl["tails"].data_ptr(), tl["aux"].data_ptr(), int(tl["max_bucket"]), anom.data_ptr(), edges.data_ptr(),
             bins.nb, thr_doy_major.data_ptr(), dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), T_out, Cn, int(c0), int(c1),
             ext.data_ptr(), n_true.data_ptr(),
         )
@@ -291,9 +288,9 @@ class HotPath:
                       binsb: Optional[torch.Tensor] = None, tails: Optional[dict] = None) -> Dict[str, object]:
         """Approximate Hobday thresholds + extreme mask of an anomaly field (detect.py:1957-2004): through tails when
         ``tails_plan`` takes the configuration, else through the bin matrix (``binsb``, made here when missing)."""
-        K = self.tails_plan(dcal, bins, q, wd, ws)
+        K = self.tails_plan(dcal, bins, q, wd, ws, anom.shape[1])
         if K is not None:
-            tl = tails if tails is not None else self.tail_extract(anom, dcal, bins, K, wsp=wsp)
+            tl = tails if tails is not None else self.tail_extract(anom, dcal, bins, wsp=wsp)
             t = self.hobday_thresholds_tails(tl, anom, dcal, bins, q, wd, ws, ny, nx, rows=rows, wsp=wsp)
             m = self.mask_ge_doy_tails(tl, anom, t["thr_doy_major"], dcal, bins, cells=cells, wsp=wsp)
             keep = (tl, t["_keep"])
@@ -379,7 +376,7 @@ class HotPath:
         ``own_rows=(row0, row1)``: the field is a latitude shard with overlap rows; thresholds and the
         mask are produced for the owned rows only (:mod:`marex_amd.dist`).
         """
-        K = self.tails_plan(dcal, bins, q, wd, ws)
+        K = self.tails_plan(dcal, bins, q, wd, ws, x.shape[1])
         a = self.shifting_baseline(x, dcal, W, S, bins if K is None else None, wsp=workspace)
         cells = None if own_rows is None else (own_rows[0] * nx, own_rows[1] * nx)
         h = self.hobday_approx(a["out"], dcal, bins, q, wd, ws, ny, nx, rows=own_rows, cells=cells, wsp=workspace,

@@ -17,14 +17,16 @@ from oracle import marex_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def tails_reference(anom, cal, edges, K):
-    """NumPy statement of the tails of ``anom`` [T_out, C]: keys[366, K, C] (descending, 0 = empty), aux[366, C]."""
+def tails_reference(anom, cal, edges):
+    """NumPy statement of the tails of ``anom`` [T_out, C]: per bucket the sorted (descending) keys of ALL its countable
+    samples, keys[366, max_bucket, C] (0 = none), and aux[366, C]."""
     nb = edges.size - 1
     T_out, C = anom.shape
+    nmax = int(np.diff(cal.doy_start).max())
     with np.errstate(invalid="ignore"):
         bins = np.digitize(anom, edges) - 1
         over = (anom >= edges[-1]) & ~np.isnan(anom)
-    keys = np.zeros((366, K, C), dtype=np.uint16)
+    keys = np.zeros((366, nmax, C), dtype=np.uint16)
     aux = np.zeros((366, C), dtype=np.uint16)
     for d in range(366):
         rows = cal.doy_rows[cal.doy_start[d]:cal.doy_start[d + 1]]
@@ -33,17 +35,20 @@ def tails_reference(anom, cal, edges, K):
         b = bins[rows]                                    # [n, C]
         valid = b < nb
         k = np.where(valid, ((b + 1) << 7) | np.arange(rows.size)[:, None], 0).astype(np.uint16)
-        k = -np.sort(-k.astype(np.int32), axis=0)         # descending
-        n = min(K, rows.size)
-        keys[d, :n] = k[:n].astype(np.uint16)
+        keys[d, :rows.size] = -np.sort(-k.astype(np.int32), axis=0)
         aux[d] = valid.sum(axis=0).astype(np.uint16) | np.where(over[rows].any(axis=0), 0x8000, 0).astype(np.uint16)
     return keys, aux
 
 
 def device_tails_to_keys(tl, C):
-    t = tl["tails"].cpu().numpy().view(np.uint16)          # [366, K/8, C, 8]
-    K = tl["K"]
-    return np.ascontiguousarray(t.transpose(0, 1, 3, 2)).reshape(366, K, C), tl["aux"].cpu().numpy().view(np.uint16)
+    """Device lists [366, NPER, 2, C, 8] -> (all keys of a bucket sorted descending [366, NPER*16, C], every list sorted?)."""
+    t = tl["tails"].cpu().numpy().view(np.uint16)          # [366, NPER, 2, C, 8]
+    nper = t.shape[1]
+    per_list = np.ascontiguousarray(t.transpose(0, 1, 2, 4, 3)).reshape(366, nper, 16, C)   # keys of list p in stored order
+    lists_sorted = bool((np.diff(per_list.astype(np.int32), axis=2) <= 0).all())
+    allk = per_list.reshape(366, nper * 16, C)
+    allk = -np.sort(-allk.astype(np.int32), axis=1)
+    return allk.astype(np.uint16), tl["aux"].cpu().numpy().view(np.uint16), lists_sorted
 
 
 def make_anomalies(T_years=12, C=300, seed=3, start="2000-01-01", sigma=0.8):
@@ -54,9 +59,8 @@ def make_anomalies(T_years=12, C=300, seed=3, start="2000-01-01", sigma=0.8):
     return tm, cal, anom, rng
 
 
-@pytest.mark.parametrize("K", [16, 32])
-@pytest.mark.parametrize("years,C", [(12, 300), (40, 257), (3, 1024)])
-def test_tail_extract_matches_its_definition(hot, K, years, C):
+@pytest.mark.parametrize("years,C", [(12, 300), (40, 257), (3, 1024), (100, 64)])
+def test_tail_extract_matches_its_definition(hot, years, C):
     tm, cal, anom, rng = make_anomalies(years, C)
     pick = rng.random(anom.shape)
     anom[pick < 0.02] = np.nan
@@ -67,18 +71,20 @@ def test_tail_extract_matches_its_definition(hot, K, years, C):
     anom[:, 6] = 0.25                                               # all samples in one bin: ties broken by position
     bt = binning.hobday_bins()
     dcal = hot.upload_calendar(cal)
-    tl = hot.tail_extract(torch.from_numpy(anom).to(hot.device), dcal, bt, K)
+    tl = hot.tail_extract(torch.from_numpy(anom).to(hot.device), dcal, bt)
     hot.sync()
-    keys, aux = device_tails_to_keys(tl, C)
-    ekeys, eaux = tails_reference(anom, cal, bt.edges, K)
+    keys, aux, lists_sorted = device_tails_to_keys(tl, C)
+    ekeys, eaux = tails_reference(anom, cal, bt.edges)
+    assert lists_sorted                                             # every list descending (consumers stop at the first miss)
     assert np.array_equal(aux, eaux)
-    assert np.array_equal(keys, ekeys)
+    n = ekeys.shape[1]
+    assert np.array_equal(keys[:, :n], ekeys) and not keys[:, n:].any()
 
 
-def _thr_case(hot, anom, cal, bt, pct, wd, ws, ny, nx, K, opts=None, rows=None):
+def _thr_case(hot, anom, cal, bt, pct, wd, ws, ny, nx, opts=None, rows=None):
     dcal = hot.upload_calendar(cal)
     ad = torch.from_numpy(anom).to(hot.device)
-    tl = hot.tail_extract(ad, dcal, bt, K)
+    tl = hot.tail_extract(ad, dcal, bt)
     hot.ctx.debug_counters(reset=True)
     with hot.ctx.options(**(opts or {})):
         t = hot.hobday_thresholds_tails(tl, ad, dcal, bt, pct / 100.0, wd, ws or 1, ny, nx, rows=rows)
@@ -100,20 +106,18 @@ def _thr_case(hot, anom, cal, bt, pct, wd, ws, ny, nx, K, opts=None, rows=None):
     return counters
 
 
-@pytest.mark.parametrize("K", [16, 32])
-def test_short_tails_reread_their_buckets(hot, K):
-    """40 samples per bucket, q = 0.6: 16 of them lie above the quantile, far more than a 16-key tail holds and close to
-    what a 32-key tail holds -- the threshold kernel has to fetch the rest from the anomalies, the mask kernel too."""
+def test_low_quantiles_walk_deep_into_the_lists(hot):
+    """40 samples per bucket (3 lists), q = 0.6: 16 samples of a bucket lie above the quantile, so second chunks are read and
+    most of every list is inside the band; q = 0.95 on the same field touches first chunks only."""
     tm, cal, anom, rng = make_anomalies(40, 12 * 20, seed=11)
     anom[:, 7] = np.nan
     bt = binning.hobday_bins()
-    c = _thr_case(hot, anom, cal, bt, 60.0, 11, 5, 12, 20, K)
-    assert c[1] > 0, c                # buckets re-read from the anomalies by the threshold kernel
-    if K == 16:
-        assert c[4] > 0, c            # 16 keys do not reach down to the 60th percentile: mask groups decided on the values
-    c = _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 12, 20, K)
-    if K == 32:
-        assert c[1] == 0, c           # K = 32 holds the top 80 % of a 40-sample bucket: no re-reads at p95
+    _thr_case(hot, anom, cal, bt, 60.0, 11, 5, 12, 20)
+    _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 12, 20)
+    # 100 samples per bucket: 7 lists (the 8-list instance of the kernel), 128 is the format's limit
+    tm, cal, anom, rng = make_anomalies(100, 6 * 10, seed=12)
+    _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 6, 10)
+    _thr_case(hot, anom, cal, bt, 90.0, 5, 3, 6, 10)
 
 
 @pytest.mark.parametrize("tile", [16, 32])
@@ -130,18 +134,18 @@ def test_seasonal_and_patchy_thresholds_move_the_band(hot, tile):
     field[:, 20:, :] += np.float32(0.3)
     anom = np.ascontiguousarray(field.reshape(cal.T_out, -1))
     bt = binning.hobday_bins()
-    c = _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 40, 36, 32, opts={"THR_TILE": tile, "THR_DD": 366})
+    c = _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 40, 36, opts={"THR_TILE": tile, "THR_DD": 366})
     assert c[0] > c[3] / 366 and c[2] > 0, c       # more rebuilds than one per block; stragglers needed extra passes
-    _thr_case(hot, anom, cal, bt, 90.0, 5, 3, 40, 36, 32, opts={"THR_TILE": tile})
+    _thr_case(hot, anom, cal, bt, 90.0, 5, 3, 40, 36, opts={"THR_TILE": tile})
 
 
 def test_owned_rows_and_unstructured(hot):
     tm, cal, anom, rng = make_anomalies(20, 23 * 31, seed=8)
     bt = binning.hobday_bins()
-    _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 23, 31, 32, rows=(2, 19))
-    _thr_case(hot, anom, cal, bt, 95.0, 11, 7, 23, 31, 32)
-    _thr_case(hot, anom[:, :700], cal, bt, 95.0, 11, None, 0, 700, 32)            # no pooling, C not a multiple of 256
-    _thr_case(hot, anom[:, :700], cal, bt, 100.0, 21, None, 0, 700, 16)           # q = 1: quantile runs off the table end
+    _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 23, 31, rows=(2, 19))
+    _thr_case(hot, anom, cal, bt, 95.0, 11, 7, 23, 31)
+    _thr_case(hot, anom[:, :700].copy(), cal, bt, 95.0, 11, None, 0, 700)            # no pooling, C not a multiple of 256
+    _thr_case(hot, anom[:, :700].copy(), cal, bt, 100.0, 21, None, 0, 700)           # q = 1: quantile runs off the table end
 
 
 def test_constant_and_extreme_data(hot):
@@ -152,5 +156,6 @@ def test_constant_and_extreme_data(hot):
     anom[:, 80:120] = np.float32(9.0)          # nothing countable: NaN thresholds, mask decided on the values
     anom[:, 120:130] = np.float32(4.985)       # the last countable bins: above the upper warning bound
     bt = binning.hobday_bins()
-    _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 10, 16, 32)
-    _thr_case(hot, anom, cal, bt, 95.0, 11, 1, 10, 16, 16)
+    c = _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 10, 16)
+    assert c[4] > 0, c            # buckets with values beyond the table: the mask looked at the anomalies
+    _thr_case(hot, anom, cal, bt, 95.0, 11, 1, 10, 16)
