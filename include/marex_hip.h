@@ -111,6 +111,16 @@ int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64
                                 int write_clim, const float* edges, int nb, int64_t T_out, float* out,
                                 uint16_t* bins, uint8_t* mask, int32_t* invalid_count);
 
+/* The same anomaly stage emitting TAILS (see below) instead of the bin matrix: the kernel sorts the keys of 16 output
+ * years at a time and writes them as one list per dayofyear; dayofyears its fast path does not take (irregular calendars,
+ * smoothing / baseline windows without a fast instance) get their lists from the anomalies afterwards -- the lists are
+ * complete either way.  doy_start / doy_rows / max_bucket describe the kept rows grouped by dayofyear (as for
+ * marex_tail_extract_f32); lists / aux as described at TAILS.  -4: nb > 511, max_bucket > 128 or C > 2^24. */
+int marex_shifting_baseline_tails_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* year_plan,
+                                      int n_cal_years, int W, int S, const float* edges, int nb, int64_t T_out, float* out,
+                                      uint8_t* mask, int32_t* invalid_count, const int32_t* doy_start, const int32_t* doy_rows,
+                                      int max_bucket, void* lists, uint16_t* aux);
+
 /*
  * Day-of-year thresholds from pooled histograms (approximate percentile method).
  * Replaces: the flox 2-D count + spatial pooling + per-cell _rolling_histogram_quantile +

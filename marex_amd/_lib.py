@@ -64,6 +64,9 @@ PROTOTYPES = {
     "marex_clear_option": (_i32, [_p, C.c_char_p]),
     "marex_debug_counters": (_i32, [_p, _p, _i32]),
     "marex_tail_lists": (_i32, [_i32]),
+    "marex_shifting_baseline_tails_f32": (
+        _i32, [_p, _p, _i64, _i64, _p, _i32, _i32, _i32, _p, _i32, _i64, _p, _p, _p, _p, _p, _i32, _p, _p],
+    ),
     "marex_tail_extract_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _p, _i32, _p, _p]),
     "marex_hobday_thresholds_tails_f32": (
         _i32,
@@ -134,6 +137,15 @@ class Context:
         if rc != 0:
             raise ProcessingError(f"marex_create(device={device}) failed with code {rc} (no usable HIP device?)")
         self.device = int(device)
+        # mirror of the context's option table for host-side switches: MAREX_<NAME>=<int> of the environment at creation
+        # (the library seeds itself the same way), then whatever set_option changes
+        self.py_opts = {}
+        for k, v in os.environ.items():
+            if k.startswith("MAREX_") and len(k) > 6:
+                try:
+                    self.py_opts[k[6:]] = int(v)
+                except ValueError:
+                    pass
 
     def close(self) -> None:
         if getattr(self, "handle", None):
@@ -161,8 +173,10 @@ class Context:
         """Set (or, with ``None``, clear) a tuning / diagnostic option of this context (include/marex_hip.h)."""
         if value is None:
             self.check(self.lib.marex_clear_option(self.handle, name.encode()), "marex_clear_option")
+            self.py_opts.pop(name, None)
         else:
             self.check(self.lib.marex_set_option(self.handle, name.encode(), int(value)), "marex_set_option")
+            self.py_opts[name] = int(value)
 
     def options(self, **opts):
         """Context manager: ``with ctx.options(THR_DD=5, THR_TILE=16): ...`` -- the options are cleared afterwards."""

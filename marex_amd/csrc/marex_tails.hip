@@ -59,7 +59,8 @@ __device__ __forceinline__ int tl_bin1(const uint4& ch, int u) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ doy_start, const int* __restrict__ doy_rows,
-               const float* __restrict__ edges, int nb, int NPER, uint4* __restrict__ lists, unsigned short* __restrict__ aux) {
+               const float* __restrict__ edges, int nb, int NPER, uint4* __restrict__ lists, unsigned short* __restrict__ aux,
+               const int* __restrict__ skip_chunks) {
     extern __shared__ float e[];  // [nb + 1]
     const int tid = threadIdx.x;
     for (int i = tid; i <= nb; i += 256) e[i] = edges[i];
@@ -90,6 +91,7 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
     const int npairs = NDOY / 2;
     const int pA = (int)blockIdx.y * npairs / (int)gridDim.y, pB = ((int)blockIdx.y + 1) * npairs / (int)gridDim.y;
     for (int pp = pA; pp < pB; ++pp) {
+        if (skip_chunks && skip_chunks[pp >> 1]) continue;  // this group of 4 dayofyears got its lists from the anomaly kernel
         const int d0 = 2 * pp, d1 = d0 + 1;
         const int s0 = doy_start[d0], n0 = doy_start[d0 + 1] - s0;
         const int s1 = doy_start[d1], n1 = doy_start[d1 + 1] - s1;
@@ -141,12 +143,15 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
 }
 
 static int tails_nper(int max_bucket) { return (max_bucket + TAIL_LIST - 1) / TAIL_LIST; }
+int marex_tail_extract_impl(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
+                            const int32_t* doy_rows, int max_bucket, const float* edges, int nb, void* lists, uint16_t* aux,
+                            const int* skip_chunks);
 
 extern "C" int marex_tail_lists(int max_bucket) { return (max_bucket < 1 || max_bucket > TAIL_MAX_BUCKET) ? -1 : tails_nper(max_bucket); }
 
-extern "C" int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
-                                      const int32_t* doy_rows, int max_bucket, const float* edges, int nb, void* lists,
-                                      uint16_t* aux) {
+int marex_tail_extract_impl(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
+                            const int32_t* doy_rows, int max_bucket, const float* edges, int nb, void* lists, uint16_t* aux,
+                            const int* skip_chunks) {
     if (!ctx) return -1;
     if (!anom || !doy_start || !doy_rows || !edges || !lists || !aux || T_out <= 0 || C <= 0)
         return fail(ctx, -1, "marex_tail_extract_f32: null pointer or empty shape");
@@ -162,10 +167,16 @@ extern "C" int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t
     {
         LaunchTimer lt(ctx, MAREX_K_TAILS);
         hipLaunchKernelGGL(k_tail_extract, dim3(ncb, chunks), dim3(256), lds, ctx->stream, anom, (long)C, doy_start, doy_rows, edges,
-                           nb, tails_nper(max_bucket), reinterpret_cast<uint4*>(lists), aux);
+                           nb, tails_nper(max_bucket), reinterpret_cast<uint4*>(lists), aux, skip_chunks);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
+}
+
+extern "C" int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
+                                      const int32_t* doy_rows, int max_bucket, const float* edges, int nb, void* lists,
+                                      uint16_t* aux) {
+    return marex_tail_extract_impl(ctx, anom, T_out, C, doy_start, doy_rows, max_bucket, edges, nb, lists, aux, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
