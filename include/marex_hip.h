@@ -111,16 +111,6 @@ int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64
                                 int write_clim, const float* edges, int nb, int64_t T_out, float* out,
                                 uint16_t* bins, uint8_t* mask, int32_t* invalid_count);
 
-/* The same anomaly stage emitting TAILS (see below) instead of the bin matrix: the kernel sorts the keys of 16 output
- * years at a time and writes them as one list per dayofyear; dayofyears its fast path does not take (irregular calendars,
- * smoothing / baseline windows without a fast instance) get their lists from the anomalies afterwards -- the lists are
- * complete either way.  doy_start / doy_rows / max_bucket describe the kept rows grouped by dayofyear (as for
- * marex_tail_extract_f32); lists / aux as described at TAILS.  -4: nb > 511, max_bucket > 128 or C > 2^24. */
-int marex_shifting_baseline_tails_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* year_plan,
-                                      int n_cal_years, int W, int S, const float* edges, int nb, int64_t T_out, float* out,
-                                      uint8_t* mask, int32_t* invalid_count, const int32_t* doy_start, const int32_t* doy_rows,
-                                      int max_bucket, void* lists, uint16_t* aux);
-
 /*
  * Day-of-year thresholds from pooled histograms (approximate percentile method).
  * Replaces: the flox 2-D count + spatial pooling + per-cell _rolling_histogram_quantile +
@@ -175,14 +165,13 @@ int marex_mask_ge_doy_bins_f32(marex_ctx* ctx, const float* anom, const uint16_t
  *   key = ((bin + 1) << 7) | pos    bin = np.digitize(anom, edges) - 1 (< nb <= 511), pos = index of the sample inside the
  *                                   bucket (output row doy_rows[doy_start[d] + pos], < 128); 0 = empty slot; samples the
  *                                   reference's histogram drops (NaN, >= edges[nb]) have no key
- *   lists  uint16, [366][NPER][2][C][8]   chunk j (0: the 8 largest, 1: the rest) of list p of bucket (d, c); a bucket's keys
- *                                   are partitioned over NPER = marex_tail_lists(max_bucket) = ceil(max_bucket / 16) lists
- *                                   of <= 16 keys, each sorted descending (which keys share a list is up to the producer)
+ *   lists  uint16, [366][NPER][4][C][8]   chunk j (0: the 8 largest .. 3: the 8 smallest) of list p of bucket (d, c); a
+ *                                   bucket's keys are partitioned over NPER = marex_tail_lists(max_bucket) =
+ *                                   ceil(max_bucket / 32) lists of <= 32 keys, each sorted descending
  *   aux    uint16, [366][C]         bits 0..9: number of keys of the bucket (= the samples the reference counts);
  *                                   bit 15: the bucket holds a non-NaN value >= edges[nb]
  * marex_tail_extract_f32 builds them from any anomaly field (rows grouped by dayofyear through doy_start / doy_rows,
- * max_bucket = rows of the largest dayofyear, <= 128).  The shifting-baseline anomaly kernel can emit them itself
- * (marex_shifting_baseline_tails_f32).
+ * max_bucket = rows of the largest dayofyear, <= 128).
  */
 int marex_tail_lists(int max_bucket);
 int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,

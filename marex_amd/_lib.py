@@ -64,9 +64,6 @@ PROTOTYPES = {
     "marex_clear_option": (_i32, [_p, C.c_char_p]),
     "marex_debug_counters": (_i32, [_p, _p, _i32]),
     "marex_tail_lists": (_i32, [_i32]),
-    "marex_shifting_baseline_tails_f32": (
-        _i32, [_p, _p, _i64, _i64, _p, _i32, _i32, _i32, _p, _i32, _i64, _p, _p, _p, _p, _p, _i32, _p, _p],
-    ),
     "marex_tail_extract_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _p, _i32, _p, _p]),
     "marex_hobday_thresholds_tails_f32": (
         _i32,

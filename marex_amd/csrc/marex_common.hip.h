@@ -56,6 +56,10 @@ struct marex_ctx {
     size_t morph_scratch_bytes = 0;
     int n_cu = 0;  // compute units of the device (queried on first use)
     std::map<std::string, int> opts;          // tuning / diagnostic options (marex_set_option; seeded from MAREX_* at creation)
+    long long* row_off = nullptr;             // device, byte offset of every kept row in dayofyear order (tail extraction)
+    size_t row_off_bytes = 0;
+    long long* row_off_mask = nullptr;        // the same for the one-byte-per-cell mask array (mask from tails)
+    size_t row_off_mask_bytes = 0;
     unsigned long long* dbg_counters = nullptr;  // device, MAREX_DBG_COUNTERS event counters of the tail kernels
 };
 

@@ -59,6 +59,8 @@ extern "C" int marex_destroy(marex_ctx* ctx) {
     if (ctx->detrend_scratch) (void)hipFree(ctx->detrend_scratch);
     if (ctx->morph_scratch) (void)hipFree(ctx->morph_scratch);
     if (ctx->dbg_counters) (void)hipFree(ctx->dbg_counters);
+    if (ctx->row_off) (void)hipFree(ctx->row_off);
+    if (ctx->row_off_mask) (void)hipFree(ctx->row_off_mask);
     delete ctx;
     return 0;
 }

@@ -53,14 +53,19 @@ __device__ __forceinline__ int tl_bin1(const uint4& ch, int u) {
 // ------------------------------------------------------------------------------------------------
 // K_X: tails of an anomaly field (the counting stage of detect.py:2622-2648 in the form the threshold and mask kernels
 // consume, see marex_tails.hip.h).  Thread = cell, two neighbouring dayofyears at a time as packed pairs: 16 rows of
-// both buckets in flight, np.digitize, keys, one 16-key sorting network per list.  Used for the anomaly methods whose
-// kernels do not emit tails themselves (fixed baselines, detrending, standardised anomalies, identify_extremes).
-// Reads every anomaly once: coalesced 256-byte row segments per wave, like the mask kernel.
+// both buckets in flight, np.digitize, keys, a 16-key sorting network per batch and a bitonic merge of two batches into
+// one 32-key list.  Reads every anomaly once: coalesced 256-byte row segments per wave, like the mask kernel.
+// The kernel is bound by instruction issue, scalar instructions included: row addresses come from a table of 64-bit
+// row offsets (one scalar load + add per row instead of a 64-bit multiply chain), full batches run without predicates.
 // ------------------------------------------------------------------------------------------------
+__global__ void k_row_offsets(const int* __restrict__ doy_rows, long T_out, long C, long long* __restrict__ off, int elem_bytes) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < T_out) off[r] = (long long)doy_rows[r] * C * (long long)elem_bytes;
+}
+
 __global__ void __launch_bounds__(256)
-k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ doy_start, const int* __restrict__ doy_rows,
-               const float* __restrict__ edges, int nb, int NPER, uint4* __restrict__ lists, unsigned short* __restrict__ aux,
-               const int* __restrict__ skip_chunks) {
+k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ doy_start, const long long* __restrict__ row_off,
+               const float* __restrict__ edges, int nb, int NPER, uint4* __restrict__ lists, unsigned short* __restrict__ aux) {
     extern __shared__ float e[];  // [nb + 1]
     const int tid = threadIdx.x;
     for (int i = tid; i <= nb; i += 256) e[i] = edges[i];
@@ -87,71 +92,96 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
     };
     const long c = (long)blockIdx.x * 256 + tid;
     const bool active = c < C;
-    const long cidx = active ? c : C - 1;
+    const unsigned lane_off = (unsigned)(active ? c : C - 1) * 4u;  // byte offset of the lane's cell inside a row
+    const char* abase = reinterpret_cast<const char*>(anom);
     const int npairs = NDOY / 2;
     const int pA = (int)blockIdx.y * npairs / (int)gridDim.y, pB = ((int)blockIdx.y + 1) * npairs / (int)gridDim.y;
     for (int pp = pA; pp < pB; ++pp) {
-        if (skip_chunks && skip_chunks[pp >> 1]) continue;  // this group of 4 dayofyears got its lists from the anomaly kernel
         const int d0 = 2 * pp, d1 = d0 + 1;
         const int s0 = doy_start[d0], n0 = doy_start[d0 + 1] - s0;
         const int s1 = doy_start[d1], n1 = doy_start[d1 + 1] - s1;
-        unsigned cnt0 = 0, cnt1 = 0, ovf0 = 0, ovf1 = 0;
+        unsigned cnt = 0, ovf = 0;  // packed: low half dayofyear d0, high half d1
         for (int p = 0; p < NPER; ++p) {
-            const int r = p * TAIL_LIST;
-            float va[16], vb[16];
+            unsigned half[2][16];
+            const bool short_list = p * TAIL_LIST + 16 >= n0 && p * TAIL_LIST + 16 >= n1;  // uniform: rows 16.. of the list do not exist
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int pos = r + u;  // uniform
-                va[u] = pos < n0 ? anom[(size_t)doy_rows[s0 + pos] * C + cidx] : nan_f();
-                vb[u] = pos < n1 ? anom[(size_t)doy_rows[s1 + pos] * C + cidx] : nan_f();
-            }
-            unsigned nw[16];
+            for (int hb = 0; hb < 2; ++hb) {  // two batches of 16 rows
+                if (hb == 1 && short_list) break;
+                const int r = p * TAIL_LIST + hb * 16;
+                float va[16], vb[16];
+                if (r + 16 <= n0 && r + 16 <= n1) {  // full batch (uniform): no predicates
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int pos = r + u;
-                const int ba = digit(va[u]), bb = digit(vb[u]);
-                const unsigned ka = ba < nb ? tail_key(ba, pos) : 0u, kb = bb < nb ? tail_key(bb, pos) : 0u;
-                cnt0 += ba < nb;
-                cnt1 += bb < nb;
-                ovf0 |= va[u] >= e_last;  // false for NaN
-                ovf1 |= vb[u] >= e_last;
-                nw[u] = ka | (kb << 16);
+                    for (int u = 0; u < 16; ++u) {
+                        va[u] = *reinterpret_cast<const float*>(abase + row_off[s0 + r + u] + lane_off);
+                        vb[u] = *reinterpret_cast<const float*>(abase + row_off[s1 + r + u] + lane_off);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int pos = r + u;  // uniform
+                        va[u] = pos < n0 ? *reinterpret_cast<const float*>(abase + row_off[s0 + pos] + lane_off) : nan_f();
+                        vb[u] = pos < n1 ? *reinterpret_cast<const float*>(abase + row_off[s1 + pos] + lane_off) : nan_f();
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int pos = r + u;
+                    const int ba = digit(va[u]), bb = digit(vb[u]);
+                    const bool oa = ba < nb, ob = bb < nb;
+                    const unsigned ka = oa ? tail_key(ba, pos) : 0u, kb = ob ? tail_key(bb, pos) : 0u;
+                    cnt += (oa ? 1u : 0u) + (ob ? 0x10000u : 0u);
+                    ovf |= (va[u] >= e_last ? 1u : 0u) | (vb[u] >= e_last ? 0x10000u : 0u);  // false for NaN
+                    half[hb][u] = ka | (kb << 16);
+                }
+                sort16_desc(half[hb]);
             }
-            sort16_desc(nw);
+            // two sorted runs -> one sorted list of 32: first ++ reverse(second) is bitonic
+            unsigned v[32];
+            if (short_list) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    v[i] = half[0][i];
+                    v[16 + i] = 0u;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    v[i] = half[0][i];
+                    v[16 + i] = half[1][15 - i];
+                }
+                bitonic_merge_desc<32>(v);
+            }
             if (active) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < TAIL_CH; ++j) {
                     uint4 w0, w1;
                     unsigned* a = reinterpret_cast<unsigned*>(&w0);
                     unsigned* b = reinterpret_cast<unsigned*>(&w1);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const unsigned x = nw[8 * j + 2 * i], y = nw[8 * j + 2 * i + 1];
+                        const unsigned x = v[8 * j + 2 * i], y = v[8 * j + 2 * i + 1];
                         a[i] = (x & 0xFFFFu) | (y << 16);
                         b[i] = (x >> 16) | (y & 0xFFFF0000u);
                     }
-                    lists[(((size_t)d0 * NPER + p) * 2 + j) * C + c] = w0;
-                    lists[(((size_t)d1 * NPER + p) * 2 + j) * C + c] = w1;
+                    lists[(((size_t)d0 * NPER + p) * TAIL_CH + j) * C + c] = w0;
+                    lists[(((size_t)d1 * NPER + p) * TAIL_CH + j) * C + c] = w1;
                 }
             }
         }
         if (active) {
-            aux[(size_t)d0 * C + c] = (unsigned short)(cnt0 | (ovf0 ? 0x8000u : 0u));
-            aux[(size_t)d1 * C + c] = (unsigned short)(cnt1 | (ovf1 ? 0x8000u : 0u));
+            aux[(size_t)d0 * C + c] = (unsigned short)((cnt & 0xFFFFu) | ((ovf & 0xFFFFu) ? 0x8000u : 0u));
+            aux[(size_t)d1 * C + c] = (unsigned short)((cnt >> 16) | ((ovf >> 16) ? 0x8000u : 0u));
         }
     }
 }
 
 static int tails_nper(int max_bucket) { return (max_bucket + TAIL_LIST - 1) / TAIL_LIST; }
-int marex_tail_extract_impl(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
-                            const int32_t* doy_rows, int max_bucket, const float* edges, int nb, void* lists, uint16_t* aux,
-                            const int* skip_chunks);
 
 extern "C" int marex_tail_lists(int max_bucket) { return (max_bucket < 1 || max_bucket > TAIL_MAX_BUCKET) ? -1 : tails_nper(max_bucket); }
 
-int marex_tail_extract_impl(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
-                            const int32_t* doy_rows, int max_bucket, const float* edges, int nb, void* lists, uint16_t* aux,
-                            const int* skip_chunks) {
+extern "C" int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
+                                      const int32_t* doy_rows, int max_bucket, const float* edges, int nb, void* lists,
+                                      uint16_t* aux) {
     if (!ctx) return -1;
     if (!anom || !doy_start || !doy_rows || !edges || !lists || !aux || T_out <= 0 || C <= 0)
         return fail(ctx, -1, "marex_tail_extract_f32: null pointer or empty shape");
@@ -159,24 +189,29 @@ int marex_tail_extract_impl(marex_ctx* ctx, const float* anom, int64_t T_out, in
     if (max_bucket < 1 || max_bucket > TAIL_MAX_BUCKET)
         return fail(ctx, -4, "marex_tail_extract_f32: dayofyear buckets must hold 1..%d rows", TAIL_MAX_BUCKET);
     if (((uintptr_t)lists & 15) != 0) return fail(ctx, -1, "marex_tail_extract_f32: lists must be 16-byte aligned");
+    if (C * 4 > 0xFFFFFFFFll) return fail(ctx, -4, "marex_tail_extract_f32: more than 2^30 cells");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t need = (size_t)T_out * sizeof(long long);
+    if (need > ctx->row_off_bytes) {
+        if (ctx->row_off) HIP_TRY(ctx, hipFree(ctx->row_off));
+        ctx->row_off = nullptr;
+        ctx->row_off_bytes = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->row_off, need));
+        ctx->row_off_bytes = need;
+    }
     const unsigned ncb = (unsigned)((C + 255) / 256);
     unsigned chunks = (2048 + ncb - 1) / ncb;  // enough workgroups to fill the chip whatever the number of cells
     chunks = chunks < 1 ? 1 : (chunks > 61 ? 61 : chunks);
     const size_t lds = (size_t)(nb + 1) * sizeof(float);
     {
         LaunchTimer lt(ctx, MAREX_K_TAILS);
-        hipLaunchKernelGGL(k_tail_extract, dim3(ncb, chunks), dim3(256), lds, ctx->stream, anom, (long)C, doy_start, doy_rows, edges,
-                           nb, tails_nper(max_bucket), reinterpret_cast<uint4*>(lists), aux, skip_chunks);
+        hipLaunchKernelGGL(k_row_offsets, dim3((unsigned)((T_out + 255) / 256)), dim3(256), 0, ctx->stream, doy_rows, (long)T_out, (long)C,
+                           ctx->row_off, (int)sizeof(float));
+        hipLaunchKernelGGL(k_tail_extract, dim3(ncb, chunks), dim3(256), lds, ctx->stream, anom, (long)C, doy_start, ctx->row_off, edges,
+                           nb, tails_nper(max_bucket), reinterpret_cast<uint4*>(lists), aux);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
-}
-
-extern "C" int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
-                                      const int32_t* doy_rows, int max_bucket, const float* edges, int nb, void* lists,
-                                      uint16_t* aux) {
-    return marex_tail_extract_impl(ctx, anom, T_out, C, doy_start, doy_rows, max_bucket, edges, nb, lists, aux, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -276,14 +311,15 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ 
     constexpr int NLP = (TT_BW + 2 + 1) / 2;  // dwords holding levels 0 .. BW+1
     const unsigned voff = (unsigned)cell * 16u;               // lane byte offset inside one chunk row of C cells
     const unsigned chunk_row = (unsigned)C * 16u;              // bytes of one chunk row (C cells)
-    const size_t day_stride = (size_t)NPER * 2 * (size_t)C;   // uint4 elements per dayofyear
+    const size_t day_stride = (size_t)NPER * TAIL_CH * (size_t)C;  // uint4 elements per dayofyear
 
     auto load_bucket = [&](int d0) {
         TailBucket<NPERT> b;
         b.d = d0;
         const tl_rsrc_t r = tl_make_rsrc(lists + (size_t)d0 * day_stride);
 #pragma unroll
-        for (int p = 0; p < NPF; ++p) b.c0[p] = (p < NPER) ? tl_load_chunk(r, voff, (unsigned)(2 * p) * chunk_row) : make_uint4(0, 0, 0, 0);
+        for (int p = 0; p < NPF; ++p)
+            b.c0[p] = (p < NPER) ? tl_load_chunk(r, voff, (unsigned)(TAIL_CH * p) * chunk_row) : make_uint4(0, 0, 0, 0);
         b.aux = aux[(size_t)d0 * C + cell];
         return b;
     };
@@ -322,19 +358,23 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ 
         uint4 extra[NPERT > NPF ? NPERT - NPF : 1];
 #pragma unroll
         for (int p = NPF; p < NPERT; ++p)
-            extra[p - NPF] = (p < NPER) ? tl_load_chunk(r, voff, (unsigned)(2 * p) * chunk_row) : make_uint4(0, 0, 0, 0);
+            extra[p - NPF] = (p < NPER) ? tl_load_chunk(r, voff, (unsigned)(TAIL_CH * p) * chunk_row) : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int p = 0; p < NPERT; ++p) {
             if (p < NPER) {  // uniform
                 const uint4 ch = p < NPF ? b.c0[p] : extra[p < NPF ? 0 : p - NPF];
                 const int n = cnt > 0 ? tl_count_above(ch, lim_rep) : 0;
                 n_in += n;
-                bump_chunk(ch, n, sgn, NPERT >= 3 ? 1 : 0);
-                if (__builtin_amdgcn_ballot_w64(n == 8) != 0) {  // the whole first chunk is inside the band: the second one too?
-                    const uint4 c1 = tl_load_chunk(r, voff, (unsigned)(2 * p + 1) * chunk_row);
-                    const int n1 = n == 8 ? tl_count_above(c1, lim_rep) : 0;
-                    n_in += n1;
-                    bump_chunk(c1, n1, sgn, 0);
+                bump_chunk(ch, n, sgn, NPERT >= 3 ? 2 : 1);
+                bool full = n == 8;  // the whole chunk is inside the band: look at the next one
+#pragma unroll
+                for (int jj = 1; jj < TAIL_CH; ++jj) {
+                    if (__builtin_amdgcn_ballot_w64(full) == 0) break;
+                    const uint4 cj = tl_load_chunk(r, voff, (unsigned)(TAIL_CH * p + jj) * chunk_row);
+                    const int nj = full ? tl_count_above(cj, lim_rep) : 0;
+                    n_in += nj;
+                    bump_chunk(cj, nj, sgn, 0);
+                    full = nj == 8;
                 }
             }
         }
@@ -714,7 +754,7 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
     }
     const int p = ws / 2;
     if (nb < 4 || nb > TAIL_MAX_NB || max_bucket < 1 || max_bucket > TAIL_MAX_BUCKET || p > 3 ||
-        (int64_t)max_bucket * wd * ws * ws > 65535 || C * 16 > 0xFFFFFFFFll / 16)
+        (int64_t)max_bucket * wd * ws * ws > 65535 || C > (1 << 24))
         return fail(ctx, -4, "marex_hobday_thresholds_tails_f32: shape outside the tail kernel (nb <= %d, buckets <= %d rows, "
                              "ws <= 7, pooled window <= 65535 samples)", TAIL_MAX_NB, TAIL_MAX_BUCKET);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -753,12 +793,12 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
     do {                                                                                                                             \
         if (NPER <= 1)                                                                                                               \
             hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 1, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
+        else if (NPER <= 2)                                                                                                          \
+            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 2, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
         else if (NPER <= 3)                                                                                                          \
             hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 3, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
-        else if (NPER <= 6)                                                                                                          \
-            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 6, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
         else                                                                                                                         \
-            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 8, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
+            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 4, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
     } while (0)
     {
         LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
@@ -787,17 +827,19 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
 
 // ------------------------------------------------------------------------------------------------
 // K_M from tails: extreme[t, c] = anom[t, c] >= thr[doy(t), c]  (detect.py:2003-2004) without reading the anomalies.
-// Every sample at or above the threshold sits at the top of one of its bucket's lists: keys whose bin lies above the bin
-// of the threshold are extremes, keys in the threshold's own bin are compared as numbers (a handful per wave and day),
-// the first key below ends the walk of a list.  Buckets holding values beyond the edge table (aux bit 15) are decided on
+// Every sample at or above the threshold sits at the top of one of its bucket's lists: the keys at or above the
+// threshold's bin are counted with packed arithmetic (they are a prefix of the sorted chunk); those above it are extremes,
+// those in it are compared as numbers (a handful per wave and day).  Buckets holding values beyond the edge table (aux bit 15) are decided on
 // the anomalies themselves (float4 rows, like the plain mask kernel).
 // Lane = 4 consecutive cells: 16-byte key chunks of 4 cells are one contiguous 64-byte run, mask stores are 4 bytes.
 // ------------------------------------------------------------------------------------------------
+template <int NPERT>
 __global__ void __launch_bounds__(256)
 k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ aux, int NPER, const float* __restrict__ anom,
              const float* __restrict__ edges, int nb, const float* __restrict__ thr, const int* __restrict__ doy_start,
-             const int* __restrict__ doy_rows, long C, long c0, long c1, unsigned char* __restrict__ out,
-             unsigned long long* __restrict__ n_true, unsigned long long* __restrict__ dbg) {
+             const int* __restrict__ doy_rows, const long long* __restrict__ row_off, const long long* __restrict__ row_off_anom,
+             long C, long c0, long c1, unsigned char* __restrict__ out, unsigned long long* __restrict__ n_true,
+             unsigned long long* __restrict__ dbg) {
     const int nchunk = (int)gridDim.y;
     const int dA = (int)blockIdx.y * NDOY / nchunk, dB = ((int)blockIdx.y + 1) * NDOY / nchunk;
     const long c = c0 + ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -808,64 +850,124 @@ k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__
         for (int d = dA; d < dB; ++d) {
             const int r0 = doy_start[d], nd = doy_start[d + 1] - r0;
             if (nd == 0) continue;
+            // every list's first chunk of the 4 cells: 64 contiguous bytes per list, all loads in flight together
+            uint4 ch[NPERT][4];
+            const uint4* row0 = lists + ((size_t)d * NPER * TAIL_CH) * C + c;
+#pragma unroll
+            for (int p = 0; p < NPERT; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ch[p][i] = p < NPER ? row0[(size_t)(p * TAIL_CH) * C + i] : make_uint4(0, 0, 0, 0);
             const float4 th4 = *reinterpret_cast<const float4*>(thr + (size_t)d * C + c);
             const float tv[4] = {th4.x, th4.y, th4.z, th4.w};
             const uint2 ax = *reinterpret_cast<const uint2*>(aux + (size_t)d * C + c);
             const unsigned av[4] = {ax.x & 0xFFFFu, ax.x >> 16, ax.y & 0xFFFFu, ax.y >> 16};
             unsigned bits[4][4];
+            unsigned lim_ge[4];  // keys > lim_ge: bin >= the threshold's bin
             int kt[4];
             bool slow = false, walk[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 bits[i][0] = bits[i][1] = bits[i][2] = bits[i][3] = 0u;
                 const bool isnum = tv[i] == tv[i];
-                kt[i] = isnum ? digitize_bin(tv[i], edges, nb, inv_width) : 0x7fff;  // NaN threshold: nothing is extreme
-                slow = slow || (isnum && (av[i] & 0x8000u));                            // values beyond the table: look at them
-                walk[i] = isnum && (av[i] & 0x3FFu) > 0;
+                kt[i] = isnum ? digitize_bin(tv[i], edges, nb, inv_width) : nb;  // NaN threshold: nothing is extreme
+                slow = slow || (isnum && (av[i] & 0x8000u));                        // values beyond the table: look at them
+                walk[i] = isnum && (av[i] & 0x3FFu) > 0 && kt[i] < nb;
+                const unsigned lim = ((unsigned)(kt[i] + 1) << TAIL_POS_BITS) - 1u;
+                lim_ge[i] = lim | (lim << 16);
             }
-            // one chunk of one cell: keys at or above the threshold's bin set their row's bit; returns "all 8 were"
-            auto scan = [&](const uint4& ch, int i) -> bool {
-                bool on = walk[i];
+            // Keys of a chunk at or above the threshold's bin are a prefix of n_ge keys; the first n_gt of them lie in higher
+            // bins (extremes), the rest sit IN the threshold's bin and are compared as numbers.  Those compares need a value
+            // from HBM: the first such key of every (list, cell) is fetched for all of them at once (one round trip per
+            // dayofyear instead of one per key); a second key in the same bin -- or a first chunk entirely above the
+            // threshold -- is rare and sends the 4-cell group to the plain compare on the anomalies.
+            auto set_prefix = [&](const uint4& q, int n, int i) {  // rows of the first n keys of q -> bits of cell i
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const unsigned key = tl_key(ch, u);
-                    const int bin = (int)(key >> TAIL_POS_BITS) - 1;  // -1 for an empty key
-                    const int pos = (int)(key & (TAIL_MAX_BUCKET - 1));
-                    on = on && bin >= kt[i];  // sorted: nothing further down reaches the threshold
+                    const bool on = n > u;
+                    if (u >= 1 && __builtin_amdgcn_ballot_w64(on) == 0) break;
                     if (on) {
-                        bool ext = bin > kt[i];
-                        if (!ext) ext = anom[(size_t)doy_rows[r0 + pos] * C + c + i] >= tv[i];  // the threshold's own bin
-                        if (ext) {
+                        const int pos = (int)(tl_key(q, u) & (TAIL_MAX_BUCKET - 1));
+#pragma unroll
+                        for (int wi = 0; wi < 4; ++wi)
+                            if ((pos >> 5) == wi) bits[i][wi] |= 1u << (pos & 31);
+                    }
+                }
+            };
+            float cand_val[NPERT][4];
+            int cand_pos[NPERT][4];
+            unsigned redo = 0;  // (list, cell) pairs the batched pass could not finish
+            if (__builtin_amdgcn_ballot_w64(!slow) != 0) {
+#pragma unroll
+                for (int p = 0; p < NPERT; ++p) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        cand_pos[p][i] = -1;
+                        cand_val[p][i] = 0.f;
+                        if (p < NPER && walk[i] && !slow) {
+                            const unsigned lgt = lim_ge[i] + (0x10001u << TAIL_POS_BITS);  // keys > lgt: bin > the threshold's bin
+                            const int n_ge = tl_count_above(ch[p][i], lim_ge[i]);
+                            const int n_gt = tl_count_above(ch[p][i], lgt);
+                            set_prefix(ch[p][i], n_gt, i);
+                            if (n_ge == 8 || n_ge - n_gt > 1) redo |= 1u << (p * 4 + i);  // the list goes on / keys share the threshold's bin
+                            if (n_ge - n_gt == 1) {  // key number n_gt: shift the sorted chunk down by n_gt keys
+                                const unsigned w[4] = {ch[p][i].x, ch[p][i].y, ch[p][i].z, ch[p][i].w};
+                                unsigned lo = w[0], hi = w[1];
+#pragma unroll
+                                for (int k = 1; k < 4; ++k)
+                                    if ((n_gt >> 1) == k) lo = w[k], hi = k < 3 ? w[k + 1] : 0u;
+                                const unsigned key = (n_gt & 1) ? (lo >> 16) : (lo & 0xFFFFu);
+                                (void)hi;
+                                cand_pos[p][i] = (int)(key & (TAIL_MAX_BUCKET - 1));
+                            }
+                        }
+                    }
+                }
+                // all candidate values in flight together
+#pragma unroll
+                for (int p = 0; p < NPERT; ++p)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (cand_pos[p][i] >= 0)
+                            cand_val[p][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(anom) + row_off_anom[r0 + cand_pos[p][i]] + (size_t)(c + i) * 4);
+#pragma unroll
+                for (int p = 0; p < NPERT; ++p)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (cand_pos[p][i] >= 0 && cand_val[p][i] >= tv[i]) {
+                            const int pos = cand_pos[p][i];
 #pragma unroll
                             for (int wi = 0; wi < 4; ++wi)
                                 if ((pos >> 5) == wi) bits[i][wi] |= 1u << (pos & 31);
                         }
-                    }
-                }
-                return on;
-            };
-            if (__builtin_amdgcn_ballot_w64(!slow) != 0) {
-                for (int p = 0; p < NPER; ++p) {
-                    const uint4* row = lists + (((size_t)d * NPER + p) * 2) * C + c;
-                    uint4 ch[4];
+                // the rare leftovers: walk the whole list key by key, one value fetch per key of the threshold's bin
+                // (setting a bit twice is harmless)
+                if (__builtin_amdgcn_ballot_w64(redo != 0u) != 0) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) ch[i] = row[i];
-                    bool more[4];
-                    bool any_more = false;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        more[i] = slow ? false : scan(ch[i], i);
-                        any_more = any_more || more[i];
-                    }
-                    if (__builtin_amdgcn_ballot_w64(any_more) != 0) {  // a first chunk entirely at or above the threshold
+                    for (int p = 0; p < NPERT; ++p)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            if (more[i]) {
-                                const uint4 c1v = row[(size_t)C + i];
-                                scan(c1v, i);
+                            if (__builtin_amdgcn_ballot_w64((redo >> (p * 4 + i)) & 1u) == 0) continue;
+                            bool on = (redo >> (p * 4 + i)) & 1u;
+                            for (int jj = 0; jj < TAIL_CH; ++jj) {
+                                if (__builtin_amdgcn_ballot_w64(on) == 0) break;
+                                const uint4 q = on ? row0[(size_t)(p * TAIL_CH + jj) * C + i] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    const unsigned key = tl_key(q, u);
+                                    const int bin = (int)(key >> TAIL_POS_BITS) - 1, pos = (int)(key & (TAIL_MAX_BUCKET - 1));
+                                    on = on && bin >= kt[i];
+                                    if (on) {
+                                        bool ext = bin > kt[i];
+                                        if (!ext) ext = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(anom) + row_off_anom[r0 + pos] + (size_t)(c + i) * 4) >= tv[i];
+                                        if (ext) {
+#pragma unroll
+                                            for (int wi = 0; wi < 4; ++wi)
+                                                if ((pos >> 5) == wi) bits[i][wi] |= 1u << (pos & 31);
+                                        }
+                                    }
+                                }
                             }
                         }
-                    }
                 }
             }
             if (slow) {
@@ -878,17 +980,31 @@ k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__
                     __builtin_nontemporal_store(m0 | (m1 << 8) | (m2 << 16) | (m3 << 24), reinterpret_cast<unsigned*>(out + off));
                 }
             } else {
+                // rows in groups of 8: eight row offsets per scalar load batch, bit positions known at compile time
+                unsigned char* obase = out + c;
 #pragma unroll
                 for (int wi = 0; wi < 4; ++wi) {
                     const unsigned b0 = bits[0][wi], b1 = bits[1][wi], b2 = bits[2][wi], b3 = bits[3][wi];
                     cnt_true += __popc(b0) + __popc(b1) + __popc(b2) + __popc(b3);
-                    const int rlo = wi * 32;
-                    if (rlo >= nd) break;
-                    const int rn = (nd - rlo) < 32 ? (nd - rlo) : 32;
-                    for (int rr = 0; rr < rn; ++rr) {
-                        const size_t off = (size_t)doy_rows[r0 + rlo + rr] * C + c;
-                        const unsigned m = ((b0 >> rr) & 1u) | (((b1 >> rr) & 1u) << 8) | (((b2 >> rr) & 1u) << 16) | (((b3 >> rr) & 1u) << 24);
-                        __builtin_nontemporal_store(m, reinterpret_cast<unsigned*>(out + off));
+                    if (wi * 32 >= nd) break;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int rlo = wi * 32 + g * 8;
+                        if (rlo >= nd) break;
+                        const unsigned q0 = b0 >> (g * 8), q1 = b1 >> (g * 8), q2 = b2 >> (g * 8), q3 = b3 >> (g * 8);
+                        const long long* ro = row_off + r0 + rlo;
+                        if (rlo + 8 <= nd) {
+#pragma unroll
+                            for (int rr = 0; rr < 8; ++rr) {
+                                const unsigned m = ((q0 >> rr) & 1u) | (((q1 >> rr) & 1u) << 8) | (((q2 >> rr) & 1u) << 16) | (((q3 >> rr) & 1u) << 24);
+                                __builtin_nontemporal_store(m, reinterpret_cast<unsigned*>(obase + ro[rr]));
+                            }
+                        } else {
+                            for (int rr = 0; rr < nd - rlo; ++rr) {
+                                const unsigned m = ((q0 >> rr) & 1u) | (((q1 >> rr) & 1u) << 8) | (((q2 >> rr) & 1u) << 16) | (((q3 >> rr) & 1u) << 24);
+                                __builtin_nontemporal_store(m, reinterpret_cast<unsigned*>(obase + ro[rr]));
+                            }
+                        }
                     }
                 }
             }
@@ -924,9 +1040,39 @@ extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, co
         unsigned chunks = (4096 + ncb - 1) / ncb;
         chunks = chunks < MASK_DOY_CHUNKS ? MASK_DOY_CHUNKS : (chunks > 61 ? 61 : chunks);
         unsigned long long* dbg = ctx_debug_counters(ctx);
-        hipLaunchKernelGGL(k_mask_tails, dim3(ncb, chunks), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4*>(lists), aux,
-                           tails_nper(max_bucket), anom, edges, nb, thr_doy_major, doy_start, doy_rows, (long)C, (long)c0, (long)c1,
-                           extreme, n_true, dbg);
+        const int NPER = tails_nper(max_bucket);
+        const uint4* tl = reinterpret_cast<const uint4*>(lists);
+        // byte offset of every kept row of the MASK array (one byte per cell) in dayofyear order
+        const size_t need = (size_t)T_out * sizeof(long long);
+        if (need > ctx->row_off_mask_bytes) {
+            if (ctx->row_off_mask) HIP_TRY(ctx, hipFree(ctx->row_off_mask));
+            ctx->row_off_mask = nullptr;
+            ctx->row_off_mask_bytes = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->row_off_mask, need));
+            ctx->row_off_mask_bytes = need;
+        }
+        hipLaunchKernelGGL(k_row_offsets, dim3((unsigned)((T_out + 255) / 256)), dim3(256), 0, ctx->stream, doy_rows, (long)T_out, (long)C,
+                           ctx->row_off_mask, 1);
+        const size_t need4 = (size_t)T_out * sizeof(long long);
+        if (need4 > ctx->row_off_bytes) {
+            if (ctx->row_off) HIP_TRY(ctx, hipFree(ctx->row_off));
+            ctx->row_off = nullptr;
+            ctx->row_off_bytes = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->row_off, need4));
+            ctx->row_off_bytes = need4;
+        }
+        hipLaunchKernelGGL(k_row_offsets, dim3((unsigned)((T_out + 255) / 256)), dim3(256), 0, ctx->stream, doy_rows, (long)T_out, (long)C,
+                           ctx->row_off, (int)sizeof(float));
+#define MAREX_MT_ARGS tl, aux, NPER, anom, edges, nb, thr_doy_major, doy_start, doy_rows, ctx->row_off_mask, ctx->row_off, (long)C, (long)c0, (long)c1, extreme, n_true, dbg
+        if (NPER <= 1)
+            hipLaunchKernelGGL(k_mask_tails<1>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, MAREX_MT_ARGS);
+        else if (NPER <= 2)
+            hipLaunchKernelGGL(k_mask_tails<2>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, MAREX_MT_ARGS);
+        else if (NPER <= 3)
+            hipLaunchKernelGGL(k_mask_tails<3>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, MAREX_MT_ARGS);
+        else
+            hipLaunchKernelGGL(k_mask_tails<4>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, MAREX_MT_ARGS);
+#undef MAREX_MT_ARGS
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;

@@ -11,12 +11,11 @@
 //                                       inside its dayofyear bucket (output row doy_rows[doy_start[d] + pos], < 128);
 //                                       0 = empty slot.  Samples the reference's histogram drops (NaN, >= edges[nb])
 //                                       have no key.
-//   lists[d][p][j][c] (uint4 = 8 keys)  chunk j (0: the 8 largest, 1: the rest) of list p of bucket (dayofyear d + 1,
-//                                       cell c).  A bucket's keys are PARTITIONED over its NPER = ceil(max_bucket / 16)
-//                                       lists of <= 16 keys, each sorted descending; which keys share a list is the
-//                                       producer's business (the anomaly kernel: 16 consecutive years; the extraction
-//                                       kernel: 16 consecutive rows).  Chunk-major: one 16-byte load per lane, contiguous
-//                                       across consecutive cells; consumers rarely touch chunk 1.
+//   lists[d][p][j][c] (uint4 = 8 keys)  chunk j (0: the 8 largest ... 3: the 8 smallest) of list p of bucket (dayofyear
+//                                       d + 1, cell c).  A bucket's keys are PARTITIONED over its NPER =
+//                                       ceil(max_bucket / 32) lists of <= 32 keys, each sorted descending (list p holds
+//                                       rows 32 p .. 32 p + 31 of the bucket).  Chunk-major: one 16-byte load per lane,
+//                                       contiguous across consecutive cells; consumers rarely go past chunk 0.
 //   aux[d][c] (uint16)                  bits 0..9: number of keys of the bucket (= the samples the reference counts);
 //                                       bit 15: the bucket holds a non-NaN value >= edges[nb] (only the mask cares)
 //
@@ -33,7 +32,8 @@
 #define TAIL_POS_BITS 7
 #define TAIL_MAX_BUCKET 128  // pos < 2^7
 #define TAIL_MAX_NB 511      // bin + 1 < 2^9
-#define TAIL_LIST 16         // keys per list
+#define TAIL_LIST 32         // keys per list
+#define TAIL_CH (TAIL_LIST / 8)  // 16-byte chunks per list
 #define TAIL_MAX_NPER (TAIL_MAX_BUCKET / TAIL_LIST)
 
 typedef unsigned short marex_us2 __attribute__((ext_vector_type(2)));

@@ -454,18 +454,12 @@ def _anomaly_core(eng, field: _Field, method_anomaly, window_year_baseline, smoo
                 details=f"no timestep is left after removing the first {window_year_baseline} years",
             )
         dcal = eng.upload_calendar(cal)
-        tails_bins = None
-        if callable(want_bins):  # decides per calendar: (bin table for the bin matrix, bin table for tails), one of them None
-            want_bins, tails_bins = want_bins(dcal, True)
-        if tails_bins is not None:  # the anomaly kernel emits the sorted key lists the threshold stage reads
-            r = eng.shifting_baseline_tails(x, dcal, int(window_year_baseline), int(smooth_days_baseline), tails_bins)
-        else:
-            r = eng.shifting_baseline(x, dcal, int(window_year_baseline), int(smooth_days_baseline), want_bins)
-        return {"anom": r["out"], "mask": r["mask"], "invalid": r["invalid_count"], "bins": r.get("bins"), "tails": r.get("tails"),
-                "cal": cal, "dcal": dcal}
+        want_bins = want_bins(dcal) if callable(want_bins) else want_bins
+        r = eng.shifting_baseline(x, dcal, int(window_year_baseline), int(smooth_days_baseline), want_bins)
+        return {"anom": r["out"], "mask": r["mask"], "invalid": r["invalid_count"], "bins": r.get("bins"), "cal": cal, "dcal": dcal}
     cal = calendar.build_calendar(field.time)
     dcal = eng.upload_calendar(cal)
-    want_bins = want_bins(dcal, False)[0] if callable(want_bins) else want_bins
+    want_bins = want_bins(dcal) if callable(want_bins) else want_bins
     if method_anomaly == "fixed_baseline":
         _check_reference_period_values(reference_period, cal.year)
         r = eng.fixed_baseline(x, dcal, reference_period, want_bins, count_invalid=True)
@@ -669,12 +663,10 @@ def preprocess_data(
     # tail kernels take most configurations and read the anomalies themselves)
     bins_for = None
     if need_bins is not None:
-        def bins_for(dcal, can_emit_tails):
+        def bins_for(dcal):
             k = eng.tails_plan(dcal, need_bins, threshold_percentile / 100.0, int(window_days_hobday), int(ws_eff) if ws_eff else 1,
                                int(fb_cells[0]))
-            if k is None:
-                return need_bins, None
-            return None, (need_bins if can_emit_tails and eng.ctx_opt("SHIFT_TAILS", 0) else None)
+            return need_bins if k is None else None
 
     fb_cells = [0]
     for sh in blocks:

@@ -182,39 +182,6 @@ class HotPath:
             res["bins"] = binsb
         return res
 
-    def shifting_baseline_tails(self, x: torch.Tensor, dcal: DeviceCalendar, W: int, S: int, bins: BinTable,
-                                wsp: Optional[dict] = None) -> Dict[str, object]:
-        """Anomaly stage emitting the sorted key lists (TAILS) of its own output: no bin matrix, no extraction pass."""
-        self._bind_stream()
-        assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
-        T, Cn = x.shape
-        cal = dcal.plan
-        if cal.T != T:
-            raise ProcessingError("calendar length does not match the time axis of x")
-        if cal.has_duplicates:
-            raise ConfigurationError(
-                "shifting_baseline needs at most one timestep per (year, dayofyear)",
-                details="sub-daily time axes are not supported by the device path",
-            )
-        T_out = cal.T_out
-        out = self._buf(wsp, "anom", (T_out, Cn), torch.float32, self.device)
-        mask = self._buf(wsp, "mask", (Cn,), torch.uint8, self.device)
-        invalid = self._buf(wsp, "invalid", (Cn,), torch.int32, self.device)
-        invalid.zero_()
-        edges = self.bin_tables(bins)[0]
-        nd = int(np.diff(cal.doy_start).max())
-        nper = (nd + 15) // 16
-        lists = self._buf(wsp, "tails", (N_DOY, nper, 2, Cn, 8), torch.int16, self.device)
-        aux = self._buf(wsp, "tails_aux", (N_DOY, Cn), torch.int16, self.device)
-        rc = self.lib.marex_shifting_baseline_tails_f32(
-            self.ctx.handle, x.data_ptr(), T, Cn, dcal.year_plan.data_ptr(), cal.n_cal_years, int(W), int(S), edges.data_ptr(),
-            bins.nb, T_out, out.data_ptr(), mask.data_ptr(), invalid.data_ptr(), dcal.doy_start.data_ptr(),
-            dcal.doy_rows.data_ptr(), nd, lists.data_ptr(), aux.data_ptr(),
-        )
-        self.ctx.check(rc, "marex_shifting_baseline_tails_f32")
-        return {"out": out, "mask": mask, "invalid_count": invalid, "_keep": edges,
-                "tails": {"tails": lists, "aux": aux, "max_bucket": nd, "_keep": edges}}
-
     # ------------------------------------------------------------------ stage a10/a11
     def hobday_thresholds(
         self,
@@ -267,7 +234,9 @@ class HotPath:
         nd = int(np.diff(dcal.plan.doy_start).max())
         if not (bins.nb <= 511 and 1 <= nd <= 128 and ws <= 7 and nd * wd * ws * ws <= 65535 and (C is None or C <= (1 << 24))):
             return None
-        return (nd + 15) // 16
+        if self.hobday_path != "tails" and nd < 24:
+            return None  # short buckets (10-yr fields): the bin-matrix kernels are the faster ones
+        return (nd + 31) // 32
 
     def tail_extract(self, anom: torch.Tensor, dcal: DeviceCalendar, bins: BinTable, wsp: Optional[dict] = None):
         """Sorted key lists of every (dayofyear, cell) bucket of ``anom`` (include/marex_hip.h, TAILS)."""
@@ -275,8 +244,8 @@ class HotPath:
         T_out, Cn = anom.shape
         edges = self.bin_tables(bins)[0]
         nd = int(np.diff(dcal.plan.doy_start).max())
-        nper = (nd + 15) // 16
-        lists = self._buf(wsp, "tails", (N_DOY, nper, 2, Cn, 8), torch.int16, self.device)
+        nper = (nd + 31) // 32
+        lists = self._buf(wsp, "tails", (N_DOY, nper, 4, Cn, 8), torch.int16, self.device)
         aux = self._buf(wsp, "tails_aux", (N_DOY, Cn), torch.int16, self.device)
         rc = self.lib.marex_tail_extract_f32(
             self.ctx.handle, anom.data_ptr(), T_out, Cn, dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), nd,
@@ -414,10 +383,7 @@ class HotPath:
         mask are produced for the owned rows only (:mod:`marex_amd.dist`).
         """
         K = self.tails_plan(dcal, bins, q, wd, ws, x.shape[1])
-        if K is not None and self.ctx_opt("SHIFT_TAILS", 0):
-            a = self.shifting_baseline_tails(x, dcal, W, S, bins, wsp=workspace)
-        else:
-            a = self.shifting_baseline(x, dcal, W, S, bins if K is None else None, wsp=workspace)
+        a = self.shifting_baseline(x, dcal, W, S, bins if K is None else None, wsp=workspace)
         cells = None if own_rows is None else (own_rows[0] * nx, own_rows[1] * nx)
         h = self.hobday_approx(a["out"], dcal, bins, q, wd, ws, ny, nx, rows=own_rows, cells=cells, wsp=workspace,
                                binsb=a.get("bins"), tails=a.get("tails"))

@@ -41,12 +41,12 @@ def tails_reference(anom, cal, edges):
 
 
 def device_tails_to_keys(tl, C):
-    """Device lists [366, NPER, 2, C, 8] -> (all keys of a bucket sorted descending [366, NPER*16, C], every list sorted?)."""
-    t = tl["tails"].cpu().numpy().view(np.uint16)          # [366, NPER, 2, C, 8]
+    """Device lists [366, NPER, 4, C, 8] -> (all keys of a bucket sorted descending [366, NPER*32, C], every list sorted?)."""
+    t = tl["tails"].cpu().numpy().view(np.uint16)          # [366, NPER, 4, C, 8]
     nper = t.shape[1]
-    per_list = np.ascontiguousarray(t.transpose(0, 1, 2, 4, 3)).reshape(366, nper, 16, C)   # keys of list p in stored order
+    per_list = np.ascontiguousarray(t.transpose(0, 1, 2, 4, 3)).reshape(366, nper, 32, C)   # keys of list p in stored order
     lists_sorted = bool((np.diff(per_list.astype(np.int32), axis=2) <= 0).all())
-    allk = per_list.reshape(366, nper * 16, C)
+    allk = per_list.reshape(366, nper * 32, C)
     allk = -np.sort(-allk.astype(np.int32), axis=1)
     return allk.astype(np.uint16), tl["aux"].cpu().numpy().view(np.uint16), lists_sorted
 
@@ -107,14 +107,14 @@ def _thr_case(hot, anom, cal, bt, pct, wd, ws, ny, nx, opts=None, rows=None):
 
 
 def test_low_quantiles_walk_deep_into_the_lists(hot):
-    """40 samples per bucket (3 lists), q = 0.6: 16 samples of a bucket lie above the quantile, so second chunks are read and
-    most of every list is inside the band; q = 0.95 on the same field touches first chunks only."""
+    """40 samples per bucket (2 lists), q = 0.6: 16 samples of a bucket lie above the quantile, so second and third chunks are
+    read and most of every list is inside the band; q = 0.95 on the same field touches first chunks only."""
     tm, cal, anom, rng = make_anomalies(40, 12 * 20, seed=11)
     anom[:, 7] = np.nan
     bt = binning.hobday_bins()
     _thr_case(hot, anom, cal, bt, 60.0, 11, 5, 12, 20)
     _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 12, 20)
-    # 100 samples per bucket: 7 lists (the 8-list instance of the kernel), 128 is the format's limit
+    # 100 samples per bucket: 4 lists (the largest instance of the kernels), 128 rows is the format's limit
     tm, cal, anom, rng = make_anomalies(100, 6 * 10, seed=12)
     _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 6, 10)
     _thr_case(hot, anom, cal, bt, 90.0, 5, 3, 6, 10)
