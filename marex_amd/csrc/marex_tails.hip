@@ -80,8 +80,17 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
         lean = lean && e_delta > 0.f && ((double)nb + 2.0 * m / (double)e_delta) * (1.0 / 1048576.0) < 1.0 / 256.0;
     }
     const float c0 = (1.0f - e_first * inv_width) - 0.0078125f, nbm1f = (float)(nb - 1);
+    const long c = (long)blockIdx.x * 256 + tid;
+    const bool active = c < C;
+    const unsigned lane_off = (unsigned)(active ? c : C - 1) * 4u;  // byte offset of the lane's cell inside a row
+    const char* abase = reinterpret_cast<const char*>(anom);
+    const int npairs = NDOY / 2;
+    const int pA = (int)blockIdx.y * npairs / (int)gridDim.y, pB = ((int)blockIdx.y + 1) * npairs / (int)gridDim.y;
+    // the whole walk once per digitize flavour (uniform choice at the top, no branch per sample)
+    auto body = [&](auto lean_tag) {
+    constexpr bool LEAN = decltype(lean_tag)::value;
     auto digit = [&](float a) -> int {
-        if (lean) {
+        if (LEAN) {
             const float f = __builtin_fmaf(a, inv_width, c0);
             const float t = __builtin_amdgcn_fmed3f(__builtin_floorf(f), 0.0f, nbm1f);
             const float ehi = e_first + t * e_delta;  // edges[t + 1], the table's own arithmetic (separately rounded)
@@ -90,12 +99,6 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
         }
         return digitize_bin(a, e, nb, inv_width);
     };
-    const long c = (long)blockIdx.x * 256 + tid;
-    const bool active = c < C;
-    const unsigned lane_off = (unsigned)(active ? c : C - 1) * 4u;  // byte offset of the lane's cell inside a row
-    const char* abase = reinterpret_cast<const char*>(anom);
-    const int npairs = NDOY / 2;
-    const int pA = (int)blockIdx.y * npairs / (int)gridDim.y, pB = ((int)blockIdx.y + 1) * npairs / (int)gridDim.y;
     for (int pp = pA; pp < pB; ++pp) {
         const int d0 = 2 * pp, d1 = d0 + 1;
         const int s0 = doy_start[d0], n0 = doy_start[d0 + 1] - s0;
@@ -173,6 +176,11 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
             aux[(size_t)d1 * C + c] = (unsigned short)((cnt >> 16) | ((ovf >> 16) ? 0x8000u : 0u));
         }
     }
+    };
+    if (lean)
+        body(std::true_type{});
+    else
+        body(std::false_type{});
 }
 
 static int tails_nper(int max_bucket) { return (max_bucket + TAIL_LIST - 1) / TAIL_LIST; }
