@@ -157,7 +157,7 @@ int marex_mask_ge_doy_bins_f32(marex_ctx* ctx, const float* anom, const uint16_t
                                int64_t C, int64_t c0, int64_t c1, uint8_t* extreme, unsigned long long* n_true);
 
 /*
- * TAILS: the default representation of the day-of-year histograms of the approximate Hobday method
+ * TAILS: the default representation of the day-of-year histograms of the approximate Hobday method for long series
  * (marEx/detect.py:2622-2648: np.digitize + the flox 2-D count by (dayofyear, bin)).  Only the upper end of a histogram
  * decides a high quantile, so instead of a dense (366 x nb) count per cell the device keeps the samples of every
  * (dayofyear, cell) bucket as 16-bit keys in short lists that are sorted descending; consumers read the top of each list
@@ -165,34 +165,45 @@ int marex_mask_ge_doy_bins_f32(marex_ctx* ctx, const float* anom, const uint16_t
  *   key = ((bin + 1) << 7) | pos    bin = np.digitize(anom, edges) - 1 (< nb <= 511), pos = index of the sample inside the
  *                                   bucket (output row doy_rows[doy_start[d] + pos], < 128); 0 = empty slot; samples the
  *                                   reference's histogram drops (NaN, >= edges[nb]) have no key
- *   lists  uint16, [366][NPER][4][C][8]   chunk j (0: the 8 largest .. 3: the 8 smallest) of list p of bucket (d, c); a
- *                                   bucket's keys are partitioned over NPER = marex_tail_lists(max_bucket) =
- *                                   ceil(max_bucket / 32) lists of <= 32 keys, each sorted descending
+ *   lists  uint16, [366][NPER][NCH][C][8]  chunk j (0: the 8 largest ...) of list p of bucket (d, c).  A bucket's keys are
+ *                                   partitioned over NPER = marex_tail_lists(max_bucket, list_rows) = ceil(max_bucket /
+ *                                   list_rows) lists of <= list_rows keys, each sorted descending, in NCH = 2 (list_rows
+ *                                   <= 16) or 4 (<= 32) chunks of 8 keys.  list_rows = 32: marex_tail_extract_f32 on any
+ *                                   anomaly field; list_rows = 15: what marex_shifting_baseline_tails_f32 emits itself
  *   aux    uint16, [366][C]         bits 0..9: number of keys of the bucket (= the samples the reference counts);
  *                                   bit 15: the bucket holds a non-NaN value >= edges[nb]
- * marex_tail_extract_f32 builds them from any anomaly field (rows grouped by dayofyear through doy_start / doy_rows,
- * max_bucket = rows of the largest dayofyear, <= 128).
+ * Rows are grouped by dayofyear through doy_start / doy_rows; max_bucket = rows of the largest dayofyear (<= 128).
  */
-int marex_tail_lists(int max_bucket);
+int marex_tail_lists(int max_bucket, int list_rows);
 int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
-                           const int32_t* doy_rows, int max_bucket, const float* edges, int nb, void* lists, uint16_t* aux);
+                           const int32_t* doy_rows, int max_bucket, const float* edges, int nb, int list_rows, void* lists,
+                           uint16_t* aux);
+
+/* The shifting-baseline anomaly stage of marex_shifting_baseline_f32 emitting TAILS (list_rows = 15) instead of the bin
+ * matrix: the kernel sorts the keys of 15 output years at a time and writes them as one list per dayofyear; dayofyears its
+ * fast path does not take (irregular calendars, smoothing / baseline windows without a fast instance) get their lists from
+ * the anomalies afterwards -- the lists are complete either way.  -4: nb > 511, max_bucket > 90 or C > 2^24. */
+int marex_shifting_baseline_tails_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* year_plan,
+                                      int n_cal_years, int W, int S, const float* edges, int nb, int64_t T_out, float* out,
+                                      uint8_t* mask, int32_t* invalid_count, const int32_t* doy_start, const int32_t* doy_rows,
+                                      int max_bucket, void* lists, uint16_t* aux);
 
 /* Day-of-year thresholds from tails: same result as marex_hobday_thresholds_f32 (detect.py:2638-2732, 2465-2559: pooled
  * counts, count-interpolated quantile, NaN where the first kept anomaly is NaN, clamp and warning statistics), arguments as
  * there plus the tails and the anomaly field they belong to (`anom`, [T_out, C]: its row 0 is first_anom).
- * Needs nb <= 511, max_bucket <= 128, ws <= 7, max_bucket*wd*ws*ws <= 65535 and C <= 2^24 (else -4: use the bin-matrix
- * entry point). */
-int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, const float* anom, int64_t T_out,
-                                      int64_t C, int ny, int nx, int max_bucket, const float* centres, int nb, double q, int wd,
-                                      int ws, float lower_bound, float upper_bound, int row0, int row1, float* thr_doy_major,
-                                      marex_thr_stats* stats);
+ * Needs nb <= 511, max_bucket <= 128 in at most 6 lists, ws <= 7, max_bucket*wd*ws*ws <= 65535 and C <= 2^24 (else -4: use
+ * the bin-matrix entry point). */
+int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, int list_rows, const float* anom,
+                                      int64_t T_out, int64_t C, int ny, int nx, int max_bucket, const float* centres, int nb,
+                                      double q, int wd, int ws, float lower_bound, float upper_bound, int row0, int row1,
+                                      float* thr_doy_major, marex_thr_stats* stats);
 
 /* The extreme mask from tails: same result as marex_mask_ge_doy_f32 (detect.py:2003-2004, 833-835) without reading the
  * anomalies, except for samples in the threshold's own bin and for buckets holding values beyond the edge table. */
-int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, int max_bucket, const float* anom,
-                                const float* edges, int nb, const float* thr_doy_major, const int32_t* doy_start,
-                                const int32_t* doy_rows, int64_t T_out, int64_t C, int64_t c0, int64_t c1, uint8_t* extreme,
-                                unsigned long long* n_true);
+int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, int list_rows, int max_bucket,
+                                const float* anom, const float* edges, int nb, const float* thr_doy_major,
+                                const int32_t* doy_start, const int32_t* doy_rows, int64_t T_out, int64_t C, int64_t c0,
+                                int64_t c1, uint8_t* extreme, unsigned long long* n_true);
 
 /*
  * Fixed-baseline anomaly (detect.py:2299-2397): clim[d, c] = float32 nanmean of x over the timesteps with

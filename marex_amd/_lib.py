@@ -63,13 +63,16 @@ PROTOTYPES = {
     "marex_set_option": (_i32, [_p, C.c_char_p, _i32]),
     "marex_clear_option": (_i32, [_p, C.c_char_p]),
     "marex_debug_counters": (_i32, [_p, _p, _i32]),
-    "marex_tail_lists": (_i32, [_i32]),
-    "marex_tail_extract_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _p, _i32, _p, _p]),
+    "marex_tail_lists": (_i32, [_i32, _i32]),
+    "marex_tail_extract_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _p, _i32, _i32, _p, _p]),
+    "marex_shifting_baseline_tails_f32": (
+        _i32, [_p, _p, _i64, _i64, _p, _i32, _i32, _i32, _p, _i32, _i64, _p, _p, _p, _p, _p, _i32, _p, _p],
+    ),
     "marex_hobday_thresholds_tails_f32": (
         _i32,
-        [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, _f64, _i32, _i32, _f32, _f32, _i32, _i32, _p, _p],
+        [_p, _p, _p, _i32, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, _f64, _i32, _i32, _f32, _f32, _i32, _i32, _p, _p],
     ),
-    "marex_mask_ge_doy_tails_f32": (_i32, [_p, _p, _p, _i32, _p, _p, _i32, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
+    "marex_mask_ge_doy_tails_f32": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _i32, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "marex_blosc_decompress_h": (_i32, [_p, _i64, _p, _i64, _p]),
     "marex_blosc_compress_h": (_i32, [_p, _i64, _i32, _i32, _i64, _p, _i64, _p]),
     "marex_lz4_decode_streams": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _p, _p]),

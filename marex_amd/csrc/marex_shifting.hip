@@ -1,5 +1,6 @@
 // marex_shifting.hip -- K_A: validation + smoothing + rolling climatology + anomaly + bins
 #include "marex_common.hip.h"
+#include "marex_tails.hip.h"
 
 // ------------------------------------------------------------------------------------------------
 // K_A: shifting-baseline anomaly  (smoothing + rolling climatology + anomaly + bins + validation)
@@ -359,6 +360,28 @@ __device__ __forceinline__ void stb_u16(rsrc_t r, unsigned voff, int soff, int v
     __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, r, (int)voff, soff, ST_AUX_U16);
 }
 
+// 16-byte list stores: descriptor words built by hand (base, no stride, unbounded, raw dword format) so that the store can
+// be issued from inline assembly TOGETHER with the wait states it needs.  A 16-byte buffer store keeps reading its data
+// registers for a few cycles; with an SGPR soffset the compiler's hazard recogniser (ROCm 7.2) inserts nothing before the
+// next VALU write of those registers and its scheduler moves a separate s_nop away -- observed on gfx950: the first dword
+// of a chunk lost in lanes 12-15 of every 16.
+typedef int tl_out_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ tl_out_rsrc_t tl_out_make_rsrc(const void* base) {
+    const unsigned long long b = (unsigned long long)base;
+    tl_out_rsrc_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xFFFFu));
+    r.z = -1;
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void tl_out_store(tl_out_rsrc_t r, unsigned voff, unsigned soff, const unsigned (&w)[4]) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 v = {w[0], w[1], w[2], w[3]};
+    const int soff_u = __builtin_amdgcn_readfirstlane((int)soff);
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 2" : : "v"(v), "v"(voff), "s"(r), "s"(soff_u) : "memory");
+}
+
 #define SHIFT_INFO_WORDS 128  // [0..91] chunk handled by the fast kernel, [92] arange edges usable
 #define CLASSIFY_SPLIT 11      // threads per chunk in k_shift_classify (92 * 11 = 1012 <= 1024)
 
@@ -418,11 +441,23 @@ __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, 
     if (t < 92) info[t] = s_ok[t] && s_edges_ok;
 }
 
-template <int W>
+// TAILS: instead of the bin matrix the kernel emits the sorted key lists of marex_tails.hip.h.  The 16 most recent output
+// years of the wave's 4 dayofyears wait as packed key pairs in LDS (one uniform slot per year, no per-lane counters);
+// every 16th year the wave sorts them (63 packed compare-exchanges per pair of dayofyears) and writes one list per
+// dayofyear as two 16-byte chunks per lane -- whole 1-KiB lines per wave, nothing is ever read back.
+#define SHIFT_LIST 15   // output years per emitted list (15 x 2 pairs x 256 B x 4 waves + one 9-KiB stage = 39 KiB: 4 workgroups per CU)
+struct TailOut {
+    uint4* lists;              // [366][NPER][2][C] chunks
+    unsigned short* aux;       // [366][C]
+    const int* doy_start;      // [367] first bin-matrix row of every dayofyear (key positions = row - doy_start)
+    int nper;
+};
+
+template <int W, bool TAILS>
 __global__ void __launch_bounds__(256)
 k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict__ year_plan, int n_cal,
              const int* __restrict__ info, int write_clim, const float* __restrict__ edges, int nb, long T_out, float* __restrict__ out, unsigned short* __restrict__ bins, unsigned char* __restrict__ mask,
-             int* __restrict__ invalid_count, int ncg, int nblk) {
+             int* __restrict__ invalid_count, int ncg, int nblk, TailOut tails) {
     int cg, bc;
     if (!xcd_swizzle(blockIdx.x, ncg, nblk, cg, bc)) return;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -431,14 +466,18 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     // The 4 waves work on 4 neighbouring chunks of the same 64 cells: the 36 rows one calendar year needs for
     // all 16 dayofyears are staged once in LDS (double buffered, loaded one year ahead) and every wave reads its
     // 24 from there -- 2.25 instead of 6 row reads per output row leave the L2.
-    __shared__ float stage[2][36 * 64];
+    // TAILS: ONE stage buffer (a second barrier per year separates its readers from the next year's writers) so that the
+    // waiting keys fit beside it at four workgroups per CU
+    constexpr int NSTAGE = TAILS ? 1 : 2;
+    __shared__ float stage[NSTAGE][36 * 64];
+    __shared__ unsigned newkeys[TAILS ? 4 : 1][2][TAILS ? SHIFT_LIST : 1][64];  // [wave][pair of dayofyears][year slot][lane]
     const bool mine = chunk < 92 && info[chunk] != 0;  // wave-uniform; the other waves only help staging
     const int d0 = mine ? chunk * 4 : 0;
     const int4* pblk = year_plan + bc * 16;  // first dayofyear of the workgroup (bc <= 22: always < 366)
     const long c = (long)cg * 64 + lane;
     const bool active = c < C;
     const unsigned cidx = active ? (unsigned)c : (unsigned)(C - 1);  // lanes beyond C duplicate the last cell
-    const bool do_bins = bins != nullptr;
+    const bool do_bins = bins != nullptr && !TAILS;
     // bin matrix: lane part of the element index relative to the wave's first 16-cell block
     const unsigned voff = cidx * 4u;  // byte offset of the lane's cell inside a (time, cell) row
     const int rowb = (int)(C * 4);    // bytes per (time, cell) row
@@ -446,7 +485,7 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     const rsrc_t rbins = make_rsrc(do_bins ? bins + (size_t)(cg * 4) * (size_t)T_out * 16 : nullptr);
 
     float e_first = 0.f, e_delta = 1.f, inv_width = 1.f;
-    if (do_bins) {
+    if (do_bins || TAILS) {
         e_first = edges[1];
         e_delta = edges[2] - edges[1];
         inv_width = (float)(nb - 1) / (edges[nb] - e_first);
@@ -470,7 +509,7 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     };
     auto stage_store = [&](int buf, const float (&nx)[9]) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) stage[buf][(9 * wave + k) * 64 + lane] = nx[k];
+        for (int k = 0; k < 9; ++k) stage[buf & (NSTAGE - 1)][(9 * wave + k) * 64 + lane] = nx[k];
     };
     int tb_next = pblk[0].x;
     {
@@ -489,6 +528,47 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
 #pragma unroll
     for (int j = 0; j < W + 2; ++j) rA[j] = rB[j] = splat2(qnan);
     int n_invalid = 0;
+    // tails: valid-key counts and "value beyond the table" flags of the 4 dayofyears (packed pairs), year slot, list index
+    unsigned t_cntA = 0, t_cntB = 0, t_ovfA = 0, t_ovfB = 0;
+    int t_slot = 0, t_list = 0;
+    int t_ds0 = 0, t_ds1 = 0, t_ds2 = 0, t_ds3 = 0;
+    if (TAILS && mine) {
+        t_ds0 = tails.doy_start[d0];
+        t_ds1 = tails.doy_start[d0 + 1 < NDOY ? d0 + 1 : NDOY - 1];
+        t_ds2 = tails.doy_start[d0 + 2 < NDOY ? d0 + 2 : NDOY - 1];
+        t_ds3 = tails.doy_start[d0 + 3 < NDOY ? d0 + 3 : NDOY - 1];
+    }
+    // sort the waiting years of both pairs and write them out as list `t_list` of the wave's dayofyears
+    auto tails_flush = [&]() {
+        const tl_out_rsrc_t rl = tl_out_make_rsrc(tails.lists + (size_t)d0 * tails.nper * 2 * (size_t)C);
+        const unsigned lvoff = cidx * 16u;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            unsigned v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = (u < SHIFT_LIST && u < t_slot) ? newkeys[wave][pr][u][lane] : 0u;  // uniform bound
+            sort16_desc(v);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // low / high halves = the pair's first / second dayofyear
+                const int di = 2 * pr + h;
+                if (d0 + di < NDOY) {  // uniform (the last chunk has two dayofyears that do not exist)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        unsigned w[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const unsigned a = v[8 * jj + 2 * i], b = v[8 * jj + 2 * i + 1];
+                            w[i] = h == 0 ? ((a & 0xFFFFu) | (b << 16)) : ((a >> 16) | (b & 0xFFFF0000u));
+                        }
+                        const int li = __builtin_amdgcn_readfirstlane((di * tails.nper + t_list) * 2 + jj);
+                        tl_out_store(rl, lvoff, (unsigned)li * (unsigned)C * 16u, w);
+                    }
+                }
+            }
+        }
+        ++t_list;
+        t_slot = 0;
+    };
 
     const int4* pp = year_plan + d0;
     const bool tail = d0 + 3 >= NDOY;  // last chunk: dayofyears 365, 366 and two that do not exist
@@ -511,17 +591,25 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
             if (stage_next) stage_load(tb_next, nx);
         }
         v2f smA = splat2(qnan), smB = splat2(qnan);
+        v2f xp[12];  // xp[m] = rows (r0 + 2m, r0 + 2m + 1), r0 = p0.x - 10
+        const bool staged = mine && p0.x >= 0 && stage_ok(tb) && p0.x == tb + 4 * wave;
+        if (staged) {
+            const float* st = &stage[y & (NSTAGE - 1)][(4 * wave) * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < 12; ++m) {
+                xp[m].x = st[(2 * m) * 64];
+                xp[m].y = st[(2 * m + 1) * 64];
+            }
+        }
+        if (TAILS) {
+            // single stage buffer: every wave has its rows in registers before anyone overwrites the buffer with the next
+            // year's (LDS traffic only: no vector-memory wait here, the row prefetch stays in flight)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         if (mine && p0.x >= 0) {
             const long r0 = (long)p0.x - 10;
-            v2f xp[12];  // xp[m] = rows (r0 + 2m, r0 + 2m + 1)
             const bool edge = r0 < 0 || r0 + 24 > T;
-            if (stage_ok(tb) && p0.x == tb + 4 * wave) {
-                const float* st = &stage[y & 1][(4 * wave) * 64 + lane];
-#pragma unroll
-                for (int m = 0; m < 12; ++m) {
-                    xp[m].x = st[(2 * m) * 64];
-                    xp[m].y = st[(2 * m + 1) * 64];
-                }
+            if (staged) {
             } else if (!edge) {
                 const rsrc_t rx = make_rsrc(x + (size_t)r0 * C);
 #pragma unroll
@@ -616,7 +704,7 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                 if (p1.x >= 0) stb_f32(ro, voff, rowb, write_clim ? climA.y : aA.y);
                 if (p2.x >= 0) stb_f32(ro, voff, 2 * rowb, write_clim ? climB.x : aB.x);
                 if (p3.x >= 0) stb_f32(ro, voff, 3 * rowb, write_clim ? climB.y : aB.y);
-                if (do_bins) {
+                if (do_bins || TAILS) {
                     // np.digitize(a, edges) - 1 on the arange table (contract C4): the guess, biased down, is the
                     // true bin or the one below (k_shift_classify checked the error bound); one comparison with
                     // the edge above it -- recomputed with the table's own arithmetic -- settles which.  A NaN
@@ -636,10 +724,25 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                     int k0, k1, k2, k3;
                     digit2(aA, k0, k1);
                     digit2(aB, k2, k3);
-                    stb_u16(rbins, bin_lane, p0.z * 32, k0);
-                    if (p1.x >= 0) stb_u16(rbins, bin_lane, p1.z * 32, k1);
-                    if (p2.x >= 0) stb_u16(rbins, bin_lane, p2.z * 32, k2);
-                    if (p3.x >= 0) stb_u16(rbins, bin_lane, p3.z * 32, k3);
+                    if (TAILS) {
+                        // keys of this year's 4 samples (0 for absent dayofyears and for samples the histogram drops)
+                        const bool v0 = k0 < nb, v1 = p1.x >= 0 && k1 < nb, v2 = p2.x >= 0 && k2 < nb, v3 = p3.x >= 0 && k3 < nb;
+                        const unsigned q0 = v0 ? tail_key(k0, p0.z - t_ds0) : 0u, q1 = v1 ? tail_key(k1, p1.z - t_ds1) : 0u;
+                        const unsigned q2 = v2 ? tail_key(k2, p2.z - t_ds2) : 0u, q3 = v3 ? tail_key(k3, p3.z - t_ds3) : 0u;
+                        newkeys[wave][0][t_slot][lane] = q0 | (q1 << 16);
+                        newkeys[wave][1][t_slot][lane] = q2 | (q3 << 16);
+                        t_cntA += (v0 ? 1u : 0u) | (v1 ? 0x10000u : 0u);
+                        t_cntB += (v2 ? 1u : 0u) | (v3 ? 0x10000u : 0u);
+                        // not counted although it is a number: a value at or beyond the last edge
+                        t_ovfA |= ((!v0 && aA.x == aA.x) ? 1u : 0u) | ((p1.x >= 0 && !v1 && aA.y == aA.y) ? 0x10000u : 0u);
+                        t_ovfB |= ((p2.x >= 0 && !v2 && aB.x == aB.x) ? 1u : 0u) | ((p3.x >= 0 && !v3 && aB.y == aB.y) ? 0x10000u : 0u);
+                        ++t_slot;  // flushed between years (main loop), outside this body's register pressure
+                    } else {
+                        stb_u16(rbins, bin_lane, p0.z * 32, k0);
+                        if (p1.x >= 0) stb_u16(rbins, bin_lane, p1.z * 32, k1);
+                        if (p2.x >= 0) stb_u16(rbins, bin_lane, p2.z * 32, k2);
+                        if (p3.x >= 0) stb_u16(rbins, bin_lane, p3.z * 32, k3);
+                    }
                 }
             }
         }
@@ -650,11 +753,26 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     };
     for (int y = 0; y < n_cal; y += 2) {
         one_year(y, std::integral_constant<int, 0>{});
+        if (TAILS && t_slot == SHIFT_LIST) tails_flush();
         if (y + 1 < n_cal) one_year(y + 1, std::integral_constant<int, 1>{});
+        if (TAILS && t_slot == SHIFT_LIST) tails_flush();
 #pragma unroll
         for (int j = 0; j < W; ++j) {
             rA[j] = rA[j + 2];
             rB[j] = rB[j + 2];
+        }
+    }
+    if (TAILS && mine) {
+        if (t_slot > 0) tails_flush();
+        while (t_list < tails.nper) tails_flush();  // dayofyears with fewer rows than the longest bucket: the remaining lists are empty
+        // lists the walk never reached (fewer output years than lists * 16 cannot happen: nper = ceil(years / 16)) are not
+        // read by anyone; the counts and flags of the 4 dayofyears:
+        if (active) {
+            const unsigned cn[4] = {t_cntA & 0xFFFFu, t_cntA >> 16, t_cntB & 0xFFFFu, t_cntB >> 16};
+            const unsigned ov[4] = {t_ovfA & 0xFFFFu, t_ovfA >> 16, t_ovfB & 0xFFFFu, t_ovfB >> 16};
+#pragma unroll
+            for (int di = 0; di < 4; ++di)
+                if (d0 + di < NDOY) tails.aux[(size_t)(d0 + di) * C + c] = (unsigned short)(cn[di] | (ov[di] ? 0x8000u : 0u));
         }
     }
     if (invalid_count && active && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
@@ -674,6 +792,7 @@ struct ShiftArgs {
     uint8_t* mask;
     int32_t* invalid_count;
     const int* skip;
+    TailOut tails;
 };
 
 template <int D, int SCAP, bool SEXACT, int WCAP, bool RREG>
@@ -695,9 +814,14 @@ static int launch_shifting(marex_ctx* ctx, const ShiftArgs& a) {
 template <int W>
 static void launch_shift_fast(marex_ctx* ctx, const ShiftArgs& a) {
     const int ncg = (int)((a.C + 63) / 64);
-    hipLaunchKernelGGL(k_shift_fast<W>, dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C,
-                       a.year_plan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask,
-                       a.invalid_count, ncg, 23);
+    if (a.tails.lists)
+        hipLaunchKernelGGL((k_shift_fast<W, true>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C,
+                           a.year_plan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask,
+                           a.invalid_count, ncg, 23, a.tails);
+    else
+        hipLaunchKernelGGL((k_shift_fast<W, false>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C,
+                           a.year_plan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask,
+                           a.invalid_count, ncg, 23, a.tails);
 }
 
 template <int D, int WCAP, bool RREG>
@@ -706,22 +830,21 @@ static int dispatch_shifting_S(marex_ctx* ctx, const ShiftArgs& a) {
     return launch_shifting<D, 1, false, WCAP, RREG>(ctx, a);  // any other smoothing width: generic row loop
 }
 
-extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
-                                           const int32_t* year_plan, int n_cal_years, int W, int S,
-                                           int write_clim, const float* edges, int nb, int64_t T_out, float* out,
-                                           uint16_t* bins, uint8_t* mask, int32_t* invalid_count) {
+static int shifting_impl(marex_ctx* ctx, const char* who, const float* x, int64_t T, int64_t C, const int32_t* year_plan,
+                         int n_cal_years, int W, int S, int write_clim, const float* edges, int nb, int64_t T_out, float* out,
+                         uint16_t* bins, uint8_t* mask, int32_t* invalid_count, TailOut tails, bool* all_fast_possible) {
     if (!ctx) return -1;
     if (!x || !year_plan || !out || T <= 0 || C <= 0 || n_cal_years <= 0)
-        return fail(ctx, -1, "marex_shifting_baseline_f32: null pointer or empty shape");
-    if (((uintptr_t)year_plan & 15) != 0) return fail(ctx, -1, "marex_shifting_baseline_f32: year_plan must be 16-byte aligned");
-    if (W < 1 || S < 1) return fail(ctx, -1, "marex_shifting_baseline_f32: W and S must be >= 1");
+        return fail(ctx, -1, "%s: null pointer or empty shape", who);
+    if (((uintptr_t)year_plan & 15) != 0) return fail(ctx, -1, "%s: year_plan must be 16-byte aligned", who);
+    if (W < 1 || S < 1) return fail(ctx, -1, "%s: W and S must be >= 1", who);
     if (S > T) S = (int)T + 1;  // every window leaves the series: all-NaN smoothing either way
-    if (W > 64) return fail(ctx, -4, "marex_shifting_baseline_f32: window_year_baseline > 64 is not supported");
-    if (bins && (!edges || nb < 4 || nb > 65534 || T_out <= 0))
-        return fail(ctx, -1, "marex_shifting_baseline_f32: binning needs edges, T_out and 4 <= nb <= 65534");
+    if (W > 64) return fail(ctx, -4, "%s: window_year_baseline > 64 is not supported", who);
+    if ((bins || tails.lists) && (!edges || nb < 4 || nb > 65534 || T_out <= 0))
+        return fail(ctx, -1, "%s: binning needs edges, T_out and 4 <= nb <= 65534", who);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ShiftArgs a{x, T, C, reinterpret_cast<const int4*>(year_plan), n_cal_years, W, S, write_clim,
-                edges, nb, T_out, out, bins, mask, invalid_count, nullptr};
+                edges, nb, T_out, out, bins, mask, invalid_count, nullptr, tails};
     // 4 dayofyears per workgroup (6 row loads per output) while the padded W-year LDS ring leaves room for two
     // workgroups per CU, otherwise one dayofyear
     const int forceD = ctx_opt(ctx, "SHIFT_D", 0);
@@ -730,11 +853,12 @@ extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64
     const bool fast_w = W == 3 || W == 4 || W == 5 || W == 6 || W == 7 || W == 10 || W == 13 || W == 15;
     const bool fast_cfg = ctx_opt(ctx, "SHIFT_FAST", 1) != 0 && S == 21 && fast_w && forceD == 0 && T >= 24 &&
                           T_out < (1 << 24) && C < (1 << 24) && MAREX_ABLATE_OPT(ctx, "SHIFT_ABLATE") == 0;
+    if (all_fast_possible) *all_fast_possible = fast_cfg;
     if (fast_cfg && !ctx->shift_info) HIP_TRY(ctx, hipMalloc((void**)&ctx->shift_info, SHIFT_INFO_WORDS * sizeof(int)));
     LaunchTimer lt(ctx, MAREX_K_SHIFTING);  // one timed region: classify + fast kernel + general kernel
     if (fast_cfg) {
         hipLaunchKernelGGL(k_shift_classify, dim3(1), dim3(1024), 0, ctx->stream, a.year_plan, n_cal_years, edges, nb,
-                           bins ? 1 : 0, 1, ctx->shift_info);
+                           (bins || tails.lists) ? 1 : 0, 1, ctx->shift_info);
         a.skip = ctx->shift_info;
         switch (W) {
             case 3: launch_shift_fast<3>(ctx, a); break;
@@ -757,4 +881,37 @@ extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64
         return forceD == 1 ? dispatch_shifting_S<1, 16, false>(ctx, a) : dispatch_shifting_S<4, 16, false>(ctx, a);
     }
     return dispatch_shifting_S<1, 64, false>(ctx, a);
+}
+
+extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
+                                           const int32_t* year_plan, int n_cal_years, int W, int S,
+                                           int write_clim, const float* edges, int nb, int64_t T_out, float* out,
+                                           uint16_t* bins, uint8_t* mask, int32_t* invalid_count) {
+    return shifting_impl(ctx, "marex_shifting_baseline_f32", x, T, C, year_plan, n_cal_years, W, S, write_clim, edges, nb, T_out, out,
+                         bins, mask, invalid_count, TailOut{nullptr, nullptr, nullptr, 0}, nullptr);
+}
+
+// defined in marex_tails.hip: extraction restricted to the dayofyear chunks a flag table does NOT mark (skip == NULL: all)
+int marex_tail_extract_impl(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
+                            const int32_t* doy_rows, int max_bucket, const float* edges, int nb, int list_rows, void* lists,
+                            uint16_t* aux, const int* skip_chunks);
+
+extern "C" int marex_shifting_baseline_tails_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* year_plan,
+                                                 int n_cal_years, int W, int S, const float* edges, int nb, int64_t T_out,
+                                                 float* out, uint8_t* mask, int32_t* invalid_count, const int32_t* doy_start,
+                                                 const int32_t* doy_rows, int max_bucket, void* lists, uint16_t* aux) {
+    if (!ctx) return -1;
+    if (!doy_start || !doy_rows || !lists || !aux) return fail(ctx, -1, "marex_shifting_baseline_tails_f32: null pointer");
+    if (nb > TAIL_MAX_NB || max_bucket < 1 || max_bucket > 6 * SHIFT_LIST || C > (1 << 24))
+        return fail(ctx, -4, "marex_shifting_baseline_tails_f32: shape outside the emitted tail format (nb <= %d, buckets <= %d rows)",
+                    TAIL_MAX_NB, 6 * SHIFT_LIST);
+    if (((uintptr_t)lists & 15) != 0) return fail(ctx, -1, "marex_shifting_baseline_tails_f32: lists must be 16-byte aligned");
+    TailOut t{reinterpret_cast<uint4*>(lists), aux, doy_start, (max_bucket + SHIFT_LIST - 1) / SHIFT_LIST};
+    bool fast = false;
+    const int rc = shifting_impl(ctx, "marex_shifting_baseline_tails_f32", x, T, C, year_plan, n_cal_years, W, S, 0, edges, nb, T_out,
+                                 out, nullptr, mask, invalid_count, t, &fast);
+    if (rc != 0) return rc;
+    // dayofyear chunks the fast kernel did not take (irregular calendars, other S / W): their tails from the anomalies
+    return marex_tail_extract_impl(ctx, out, T_out, C, doy_start, doy_rows, max_bucket, edges, nb, SHIFT_LIST, lists, aux,
+                                   fast ? ctx->shift_info : nullptr);
 }

@@ -65,8 +65,10 @@ __global__ void k_row_offsets(const int* __restrict__ doy_rows, long T_out, long
 
 __global__ void __launch_bounds__(256)
 k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ doy_start, const long long* __restrict__ row_off,
-               const float* __restrict__ edges, int nb, int NPER, uint4* __restrict__ lists, unsigned short* __restrict__ aux) {
+               const float* __restrict__ edges, int nb, int NPER, int list_rows, uint4* __restrict__ lists,
+               unsigned short* __restrict__ aux, const int* __restrict__ skip_chunks) {
     extern __shared__ float e[];  // [nb + 1]
+    const int nch = list_rows <= 16 ? 2 : 4;  // 16-byte chunks per list
     const int tid = threadIdx.x;
     for (int i = tid; i <= nb; i += 256) e[i] = edges[i];
     __syncthreads();
@@ -100,19 +102,22 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
         return digitize_bin(a, e, nb, inv_width);
     };
     for (int pp = pA; pp < pB; ++pp) {
+        if (skip_chunks && skip_chunks[pp >> 1]) continue;  // this group of 4 dayofyears got its lists from the anomaly kernel
         const int d0 = 2 * pp, d1 = d0 + 1;
         const int s0 = doy_start[d0], n0 = doy_start[d0 + 1] - s0;
         const int s1 = doy_start[d1], n1 = doy_start[d1 + 1] - s1;
         unsigned cnt = 0, ovf = 0;  // packed: low half dayofyear d0, high half d1
         for (int p = 0; p < NPER; ++p) {
             unsigned half[2][16];
-            const bool short_list = p * TAIL_LIST + 16 >= n0 && p * TAIL_LIST + 16 >= n1;  // uniform: rows 16.. of the list do not exist
+            const int l0 = p * list_rows, l1 = l0 + list_rows;  // rows of this list
+            const int e0 = n0 < l1 ? n0 : l1, e1 = n1 < l1 ? n1 : l1;  // ... that exist in either bucket
+            const bool short_list = l0 + 16 >= e0 && l0 + 16 >= e1;  // uniform: rows 16.. of the list do not exist
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {  // two batches of 16 rows
                 if (hb == 1 && short_list) break;
-                const int r = p * TAIL_LIST + hb * 16;
+                const int r = l0 + hb * 16;
                 float va[16], vb[16];
-                if (r + 16 <= n0 && r + 16 <= n1) {  // full batch (uniform): no predicates
+                if (r + 16 <= e0 && r + 16 <= e1) {  // full batch (uniform): no predicates
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
                         va[u] = *reinterpret_cast<const float*>(abase + row_off[s0 + r + u] + lane_off);
@@ -122,8 +127,8 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
                         const int pos = r + u;  // uniform
-                        va[u] = pos < n0 ? *reinterpret_cast<const float*>(abase + row_off[s0 + pos] + lane_off) : nan_f();
-                        vb[u] = pos < n1 ? *reinterpret_cast<const float*>(abase + row_off[s1 + pos] + lane_off) : nan_f();
+                        va[u] = pos < e0 ? *reinterpret_cast<const float*>(abase + row_off[s0 + pos] + lane_off) : nan_f();
+                        vb[u] = pos < e1 ? *reinterpret_cast<const float*>(abase + row_off[s1 + pos] + lane_off) : nan_f();
                     }
                 }
 #pragma unroll
@@ -156,7 +161,8 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
             }
             if (active) {
 #pragma unroll
-                for (int j = 0; j < TAIL_CH; ++j) {
+                for (int j = 0; j < 4; ++j) {
+                    if (j >= nch) break;
                     uint4 w0, w1;
                     unsigned* a = reinterpret_cast<unsigned*>(&w0);
                     unsigned* b = reinterpret_cast<unsigned*>(&w1);
@@ -166,8 +172,8 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
                         a[i] = (x & 0xFFFFu) | (y << 16);
                         b[i] = (x >> 16) | (y & 0xFFFF0000u);
                     }
-                    lists[(((size_t)d0 * NPER + p) * TAIL_CH + j) * C + c] = w0;
-                    lists[(((size_t)d1 * NPER + p) * TAIL_CH + j) * C + c] = w1;
+                    lists[(((size_t)d0 * NPER + p) * nch + j) * C + c] = w0;
+                    lists[(((size_t)d1 * NPER + p) * nch + j) * C + c] = w1;
                 }
             }
         }
@@ -183,19 +189,28 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
         body(std::false_type{});
 }
 
-static int tails_nper(int max_bucket) { return (max_bucket + TAIL_LIST - 1) / TAIL_LIST; }
+static bool tails_geometry(int max_bucket, int list_rows, int& nper, int& nch) {
+    if (max_bucket < 1 || max_bucket > TAIL_MAX_BUCKET || list_rows < 8 || list_rows > 32) return false;
+    nper = (max_bucket + list_rows - 1) / list_rows;
+    nch = list_rows <= 16 ? 2 : 4;
+    return true;
+}
 
-extern "C" int marex_tail_lists(int max_bucket) { return (max_bucket < 1 || max_bucket > TAIL_MAX_BUCKET) ? -1 : tails_nper(max_bucket); }
+extern "C" int marex_tail_lists(int max_bucket, int list_rows) {
+    int nper, nch;
+    return tails_geometry(max_bucket, list_rows, nper, nch) ? nper : -1;
+}
 
-extern "C" int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
-                                      const int32_t* doy_rows, int max_bucket, const float* edges, int nb, void* lists,
-                                      uint16_t* aux) {
+int marex_tail_extract_impl(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
+                            const int32_t* doy_rows, int max_bucket, const float* edges, int nb, int list_rows, void* lists,
+                            uint16_t* aux, const int* skip_chunks) {
     if (!ctx) return -1;
     if (!anom || !doy_start || !doy_rows || !edges || !lists || !aux || T_out <= 0 || C <= 0)
         return fail(ctx, -1, "marex_tail_extract_f32: null pointer or empty shape");
     if (nb < 4 || nb > TAIL_MAX_NB) return fail(ctx, -4, "marex_tail_extract_f32: nb must be in 4..%d", TAIL_MAX_NB);
-    if (max_bucket < 1 || max_bucket > TAIL_MAX_BUCKET)
-        return fail(ctx, -4, "marex_tail_extract_f32: dayofyear buckets must hold 1..%d rows", TAIL_MAX_BUCKET);
+    int nper, nch;
+    if (!tails_geometry(max_bucket, list_rows, nper, nch))
+        return fail(ctx, -4, "marex_tail_extract_f32: dayofyear buckets must hold 1..%d rows, lists 8..32 rows", TAIL_MAX_BUCKET);
     if (((uintptr_t)lists & 15) != 0) return fail(ctx, -1, "marex_tail_extract_f32: lists must be 16-byte aligned");
     if (C * 4 > 0xFFFFFFFFll) return fail(ctx, -4, "marex_tail_extract_f32: more than 2^30 cells");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -216,10 +231,16 @@ extern "C" int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t
         hipLaunchKernelGGL(k_row_offsets, dim3((unsigned)((T_out + 255) / 256)), dim3(256), 0, ctx->stream, doy_rows, (long)T_out, (long)C,
                            ctx->row_off, (int)sizeof(float));
         hipLaunchKernelGGL(k_tail_extract, dim3(ncb, chunks), dim3(256), lds, ctx->stream, anom, (long)C, doy_start, ctx->row_off, edges,
-                           nb, tails_nper(max_bucket), reinterpret_cast<uint4*>(lists), aux);
+                           nb, nper, list_rows, reinterpret_cast<uint4*>(lists), aux, skip_chunks);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
+}
+
+extern "C" int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
+                                      const int32_t* doy_rows, int max_bucket, const float* edges, int nb, int list_rows,
+                                      void* lists, uint16_t* aux) {
+    return marex_tail_extract_impl(ctx, anom, T_out, C, doy_start, doy_rows, max_bucket, edges, nb, list_rows, lists, aux, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -258,7 +279,7 @@ struct TailBucket {
 
 template <int P, int TC, int NT, int NPERT, int TR_ = NT / TC>
 __global__ void __launch_bounds__(NT, NT == 256 ? 4 : (NT == 512 ? 2 : 1))
-k_thr_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ aux, int NPER, const float* __restrict__ anom,
+k_thr_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ aux, int NPER, int nch, const float* __restrict__ anom,
             long C, int ny, int nx, int row0, int row1, int tiles_x, int Dd, const float* __restrict__ centres, int nb, double q,
             int wd, float lower_bound, float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats,
             unsigned long long* __restrict__ dbg) {
@@ -319,7 +340,7 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ 
     constexpr int NLP = (TT_BW + 2 + 1) / 2;  // dwords holding levels 0 .. BW+1
     const unsigned voff = (unsigned)cell * 16u;               // lane byte offset inside one chunk row of C cells
     const unsigned chunk_row = (unsigned)C * 16u;              // bytes of one chunk row (C cells)
-    const size_t day_stride = (size_t)NPER * TAIL_CH * (size_t)C;  // uint4 elements per dayofyear
+    const size_t day_stride = (size_t)NPER * nch * (size_t)C;  // uint4 elements per dayofyear
 
     auto load_bucket = [&](int d0) {
         TailBucket<NPERT> b;
@@ -327,7 +348,7 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ 
         const tl_rsrc_t r = tl_make_rsrc(lists + (size_t)d0 * day_stride);
 #pragma unroll
         for (int p = 0; p < NPF; ++p)
-            b.c0[p] = (p < NPER) ? tl_load_chunk(r, voff, (unsigned)(TAIL_CH * p) * chunk_row) : make_uint4(0, 0, 0, 0);
+            b.c0[p] = (p < NPER) ? tl_load_chunk(r, voff, (unsigned)(nch * p) * chunk_row) : make_uint4(0, 0, 0, 0);
         b.aux = aux[(size_t)d0 * C + cell];
         return b;
     };
@@ -363,28 +384,33 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ 
         const unsigned lim_rep = lim | (lim << 16);
         const tl_rsrc_t r = tl_make_rsrc(lists + (size_t)b.d * day_stride);
         int n_in = 0;
-        uint4 extra[NPERT > NPF ? NPERT - NPF : 1];
+        // one list: count the keys of its first chunk that lie inside the band, bump them, go on to the next chunk while
+        // a whole chunk was inside
+        auto one_list = [&](const uint4& ch, int p) {
+            const int n = cnt > 0 ? tl_count_above(ch, lim_rep) : 0;
+            n_in += n;
+            bump_chunk(ch, n, sgn, NPERT >= 3 ? 2 : 1);
+            bool full = n == 8;
 #pragma unroll
-        for (int p = NPF; p < NPERT; ++p)
-            extra[p - NPF] = (p < NPER) ? tl_load_chunk(r, voff, (unsigned)(TAIL_CH * p) * chunk_row) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int p = 0; p < NPERT; ++p) {
-            if (p < NPER) {  // uniform
-                const uint4 ch = p < NPF ? b.c0[p] : extra[p < NPF ? 0 : p - NPF];
-                const int n = cnt > 0 ? tl_count_above(ch, lim_rep) : 0;
-                n_in += n;
-                bump_chunk(ch, n, sgn, NPERT >= 3 ? 2 : 1);
-                bool full = n == 8;  // the whole chunk is inside the band: look at the next one
-#pragma unroll
-                for (int jj = 1; jj < TAIL_CH; ++jj) {
-                    if (__builtin_amdgcn_ballot_w64(full) == 0) break;
-                    const uint4 cj = tl_load_chunk(r, voff, (unsigned)(TAIL_CH * p + jj) * chunk_row);
-                    const int nj = full ? tl_count_above(cj, lim_rep) : 0;
-                    n_in += nj;
-                    bump_chunk(cj, nj, sgn, 0);
-                    full = nj == 8;
-                }
+            for (int jj = 1; jj < 4; ++jj) {
+                if (jj >= nch || __builtin_amdgcn_ballot_w64(full) == 0) break;
+                const uint4 cj = tl_load_chunk(r, voff, (unsigned)(nch * p + jj) * chunk_row);
+                const int nj = full ? tl_count_above(cj, lim_rep) : 0;
+                n_in += nj;
+                bump_chunk(cj, nj, sgn, 0);
+                full = nj == 8;
             }
+        };
+#pragma unroll
+        for (int p = 0; p < NPF; ++p)
+            if (p < NPER) one_list(b.c0[p], p);
+        // the lists that were not prefetched: two first chunks in flight at a time
+#pragma nounroll
+        for (int p = NPF; p < NPER; p += 2) {  // uniform trip count
+            const uint4 e0 = tl_load_chunk(r, voff, (unsigned)(nch * p) * chunk_row);
+            const uint4 e1 = p + 1 < NPER ? tl_load_chunk(r, voff, (unsigned)(nch * (p + 1)) * chunk_row) : make_uint4(0, 0, 0, 0);
+            one_list(e0, p);
+            if (p + 1 < NPER) one_list(e1, p + 1);
         }
         const int below = cnt - n_in;  // everything under the band
         if (below > 0) __hip_atomic_fetch_add((lds_u32*)(size_t)col_lds, (unsigned)(sgn > 0 ? below : -below), __ATOMIC_RELAXED,
@@ -739,8 +765,9 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ 
     }
 }
 
-extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, const float* anom,
-                                                 int64_t T_out, int64_t C, int ny, int nx, int max_bucket, const float* centres,
+extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, int list_rows,
+                                                 const float* anom, int64_t T_out, int64_t C, int ny, int nx, int max_bucket,
+                                                 const float* centres,
                                                  int nb, double q, int wd, int ws, float lower_bound, float upper_bound, int row0,
                                                  int row1, float* thr_doy_major, marex_thr_stats* stats) {
     if (!ctx) return -1;
@@ -766,7 +793,9 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
         return fail(ctx, -4, "marex_hobday_thresholds_tails_f32: shape outside the tail kernel (nb <= %d, buckets <= %d rows, "
                              "ws <= 7, pooled window <= 65535 samples)", TAIL_MAX_NB, TAIL_MAX_BUCKET);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int NPER = tails_nper(max_bucket);
+    int NPER, nch;
+    if (!tails_geometry(max_bucket, list_rows, NPER, nch) || NPER > 6)
+        return fail(ctx, -4, "marex_hobday_thresholds_tails_f32: %d rows per bucket in lists of %d: more than 6 lists", max_bucket, list_rows);
     const int tile_pref = ctx_opt(ctx, "THR_TILE", (ny > 0 && p > 0 && max_bucket >= 24) ? 32 : 16);
     const bool big = (ny > 0 && p > 0) && tile_pref == 32 && (row1 - row0) >= 16 && nx >= 16;
     const int NT = big ? 1024 : 256;
@@ -796,17 +825,15 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((NDOY + Dd - 1) / Dd));
     unsigned long long* dbg = ctx_debug_counters(ctx);
     const uint4* tl = reinterpret_cast<const uint4*>(lists);
-#define MAREX_TT_ARGS tl, aux, NPER, anom, (long)C, ny, nx, row0, row1, tiles_x, Dd, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats, dbg
+#define MAREX_TT_ARGS tl, aux, NPER, nch, anom, (long)C, ny, nx, row0, row1, tiles_x, Dd, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats, dbg
 #define MAREX_TT_LAUNCH(PP, TCC, NTT, ...)                                                                                           \
     do {                                                                                                                             \
         if (NPER <= 1)                                                                                                               \
             hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 1, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
         else if (NPER <= 2)                                                                                                          \
             hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 2, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
-        else if (NPER <= 3)                                                                                                          \
+        else /* two lists prefetched across the barrier, the others loaded at use */                                                 \
             hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 3, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
-        else                                                                                                                         \
-            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 4, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
     } while (0)
     {
         LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
@@ -841,9 +868,9 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
 // the anomalies themselves (float4 rows, like the plain mask kernel).
 // Lane = 4 consecutive cells: 16-byte key chunks of 4 cells are one contiguous 64-byte run, mask stores are 4 bytes.
 // ------------------------------------------------------------------------------------------------
-template <int NPERT>
+template <int NPERT>  // lists handled per group (their first chunks are in flight together)
 __global__ void __launch_bounds__(256)
-k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ aux, int NPER, const float* __restrict__ anom,
+k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ aux, int NPER_all, int nch, const float* __restrict__ anom,
              const float* __restrict__ edges, int nb, const float* __restrict__ thr, const int* __restrict__ doy_start,
              const int* __restrict__ doy_rows, const long long* __restrict__ row_off, const long long* __restrict__ row_off_anom,
              long C, long c0, long c1, unsigned char* __restrict__ out, unsigned long long* __restrict__ n_true,
@@ -858,13 +885,6 @@ k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__
         for (int d = dA; d < dB; ++d) {
             const int r0 = doy_start[d], nd = doy_start[d + 1] - r0;
             if (nd == 0) continue;
-            // every list's first chunk of the 4 cells: 64 contiguous bytes per list, all loads in flight together
-            uint4 ch[NPERT][4];
-            const uint4* row0 = lists + ((size_t)d * NPER * TAIL_CH) * C + c;
-#pragma unroll
-            for (int p = 0; p < NPERT; ++p)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ch[p][i] = p < NPER ? row0[(size_t)(p * TAIL_CH) * C + i] : make_uint4(0, 0, 0, 0);
             const float4 th4 = *reinterpret_cast<const float4*>(thr + (size_t)d * C + c);
             const float tv[4] = {th4.x, th4.y, th4.z, th4.w};
             const uint2 ax = *reinterpret_cast<const uint2*>(aux + (size_t)d * C + c);
@@ -901,10 +921,20 @@ k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__
                     }
                 }
             };
+            if (__builtin_amdgcn_ballot_w64(!slow) != 0)
+            for (int pg = 0; pg < NPER_all; pg += NPERT) {  // lists in groups of NPERT
+                const int NPER = (NPER_all - pg) < NPERT ? (NPER_all - pg) : NPERT;
+                // every list's first chunk of the 4 cells: 64 contiguous bytes per list, all loads in flight together
+                uint4 ch[NPERT][4];
+                const uint4* row0 = lists + (((size_t)d * NPER_all + pg) * nch) * C + c;
+#pragma unroll
+                for (int p = 0; p < NPERT; ++p)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ch[p][i] = p < NPER ? row0[(size_t)(p * nch) * C + i] : make_uint4(0, 0, 0, 0);
             float cand_val[NPERT][4];
             int cand_pos[NPERT][4];
             unsigned redo = 0;  // (list, cell) pairs the batched pass could not finish
-            if (__builtin_amdgcn_ballot_w64(!slow) != 0) {
+            {
 #pragma unroll
                 for (int p = 0; p < NPERT; ++p) {
 #pragma unroll
@@ -956,9 +986,9 @@ k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__
                         for (int i = 0; i < 4; ++i) {
                             if (__builtin_amdgcn_ballot_w64((redo >> (p * 4 + i)) & 1u) == 0) continue;
                             bool on = (redo >> (p * 4 + i)) & 1u;
-                            for (int jj = 0; jj < TAIL_CH; ++jj) {
+                            for (int jj = 0; jj < nch; ++jj) {
                                 if (__builtin_amdgcn_ballot_w64(on) == 0) break;
-                                const uint4 q = on ? row0[(size_t)(p * TAIL_CH + jj) * C + i] : make_uint4(0, 0, 0, 0);
+                                const uint4 q = on ? row0[(size_t)(p * nch + jj) * C + i] : make_uint4(0, 0, 0, 0);
 #pragma unroll
                                 for (int u = 0; u < 8; ++u) {
                                     const unsigned key = tl_key(q, u);
@@ -978,6 +1008,7 @@ k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__
                         }
                 }
             }
+            }  // list groups
             if (slow) {
                 ++n_slow;
                 for (int r = 0; r < nd; ++r) {
@@ -1028,7 +1059,8 @@ k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__
     }
 }
 
-extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, int max_bucket, const float* anom,
+extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, int list_rows, int max_bucket,
+                                           const float* anom,
                                            const float* edges, int nb, const float* thr_doy_major, const int32_t* doy_start,
                                            const int32_t* doy_rows, int64_t T_out, int64_t C, int64_t c0, int64_t c1,
                                            uint8_t* extreme, unsigned long long* n_true) {
@@ -1036,7 +1068,9 @@ extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, co
     if (!lists || !aux || !anom || !edges || !thr_doy_major || !doy_start || !doy_rows || !extreme || T_out <= 0 || C <= 0 || nb < 4)
         return fail(ctx, -1, "marex_mask_ge_doy_tails_f32: null pointer or empty shape");
     if (c0 < 0 || c1 > C || c0 >= c1) return fail(ctx, -1, "marex_mask_ge_doy_tails_f32: need 0 <= c0 < c1 <= C");
-    if (max_bucket < 1 || max_bucket > TAIL_MAX_BUCKET) return fail(ctx, -4, "marex_mask_ge_doy_tails_f32: buckets must hold 1..%d rows", TAIL_MAX_BUCKET);
+    int NPER, nch;
+    if (!tails_geometry(max_bucket, list_rows, NPER, nch))
+        return fail(ctx, -4, "marex_mask_ge_doy_tails_f32: buckets must hold 1..%d rows, lists 8..32 rows", TAIL_MAX_BUCKET);
     const bool vec = (C % 4 == 0) && (c0 % 4 == 0) && (c1 % 4 == 0) && (((uintptr_t)anom | (uintptr_t)thr_doy_major) % 16 == 0) &&
                      ((uintptr_t)extreme % 4 == 0) && ((uintptr_t)aux % 8 == 0) && nb < 0x7fff;
     if (!vec)  // shapes the 4-cell kernel does not cover: the plain compare on the anomalies
@@ -1048,7 +1082,6 @@ extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, co
         unsigned chunks = (4096 + ncb - 1) / ncb;
         chunks = chunks < MASK_DOY_CHUNKS ? MASK_DOY_CHUNKS : (chunks > 61 ? 61 : chunks);
         unsigned long long* dbg = ctx_debug_counters(ctx);
-        const int NPER = tails_nper(max_bucket);
         const uint4* tl = reinterpret_cast<const uint4*>(lists);
         // byte offset of every kept row of the MASK array (one byte per cell) in dayofyear order
         const size_t need = (size_t)T_out * sizeof(long long);
@@ -1071,15 +1104,13 @@ extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, co
         }
         hipLaunchKernelGGL(k_row_offsets, dim3((unsigned)((T_out + 255) / 256)), dim3(256), 0, ctx->stream, doy_rows, (long)T_out, (long)C,
                            ctx->row_off, (int)sizeof(float));
-#define MAREX_MT_ARGS tl, aux, NPER, anom, edges, nb, thr_doy_major, doy_start, doy_rows, ctx->row_off_mask, ctx->row_off, (long)C, (long)c0, (long)c1, extreme, n_true, dbg
+#define MAREX_MT_ARGS tl, aux, NPER, nch, anom, edges, nb, thr_doy_major, doy_start, doy_rows, ctx->row_off_mask, ctx->row_off, (long)C, (long)c0, (long)c1, extreme, n_true, dbg
         if (NPER <= 1)
             hipLaunchKernelGGL(k_mask_tails<1>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, MAREX_MT_ARGS);
-        else if (NPER <= 2)
+        else if (NPER == 2 || NPER == 4)
             hipLaunchKernelGGL(k_mask_tails<2>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, MAREX_MT_ARGS);
-        else if (NPER <= 3)
+        else  // 3 lists at once; 5, 6, ... lists in groups of 3
             hipLaunchKernelGGL(k_mask_tails<3>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, MAREX_MT_ARGS);
-        else
-            hipLaunchKernelGGL(k_mask_tails<4>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, MAREX_MT_ARGS);
 #undef MAREX_MT_ARGS
     }
     HIP_TRY(ctx, hipGetLastError());

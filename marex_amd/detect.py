@@ -454,9 +454,16 @@ def _anomaly_core(eng, field: _Field, method_anomaly, window_year_baseline, smoo
                 details=f"no timestep is left after removing the first {window_year_baseline} years",
             )
         dcal = eng.upload_calendar(cal)
-        want_bins = want_bins(dcal) if callable(want_bins) else want_bins
-        r = eng.shifting_baseline(x, dcal, int(window_year_baseline), int(smooth_days_baseline), want_bins)
-        return {"anom": r["out"], "mask": r["mask"], "invalid": r["invalid_count"], "bins": r.get("bins"), "cal": cal, "dcal": dcal}
+        tails_bins = None
+        if callable(want_bins):
+            tails_bins = want_bins(dcal, "tails")  # bin table when the anomaly kernel should emit the sorted key lists itself
+            want_bins = want_bins(dcal)
+        if tails_bins is not None:
+            r = eng.shifting_baseline_tails(x, dcal, int(window_year_baseline), int(smooth_days_baseline), tails_bins)
+        else:
+            r = eng.shifting_baseline(x, dcal, int(window_year_baseline), int(smooth_days_baseline), want_bins)
+        return {"anom": r["out"], "mask": r["mask"], "invalid": r["invalid_count"], "bins": r.get("bins"), "tails": r.get("tails"),
+                "cal": cal, "dcal": dcal}
     cal = calendar.build_calendar(field.time)
     dcal = eng.upload_calendar(cal)
     want_bins = want_bins(dcal) if callable(want_bins) else want_bins
@@ -663,9 +670,11 @@ def preprocess_data(
     # tail kernels take most configurations and read the anomalies themselves)
     bins_for = None
     if need_bins is not None:
-        def bins_for(dcal):
+        def bins_for(dcal, what="bins"):
             k = eng.tails_plan(dcal, need_bins, threshold_percentile / 100.0, int(window_days_hobday), int(ws_eff) if ws_eff else 1,
                                int(fb_cells[0]))
+            if what == "tails":
+                return need_bins if (k is not None and eng.shifting_tails_ok(dcal)) else None
             return need_bins if k is None else None
 
     fb_cells = [0]

@@ -55,12 +55,19 @@ class HotPath:
         self.hobday_path: Optional[str] = None
         self._bind_stream()
 
+    #: tests set this: fresh output buffers are filled with a byte pattern, so that an element a kernel forgets to write
+    #: shows up as garbage instead of as the zeros a fresh allocation often holds
+    POISON = False
+
     @staticmethod
     def _buf(wsp: Optional[dict], name: str, shape, dtype, device) -> torch.Tensor:
         """Output buffer: fresh when ``wsp`` is None, otherwise cached in the workspace dict and reused
         (no allocator traffic in the steady state, outputs of the previous call are overwritten)."""
         if wsp is None:
-            return torch.empty(shape, dtype=dtype, device=device)
+            t = torch.empty(shape, dtype=dtype, device=device)
+            if HotPath.POISON and t.numel():
+                t.view(torch.uint8).fill_(0xCD)
+            return t
         n = 1
         for d in shape:
             n *= int(d)
@@ -226,9 +233,13 @@ class HotPath:
         }
 
     # ------------------------------------------------------------------ stage a10/a11 on tails (default)
+    #: rows per sorted list: what the extraction kernel writes / what the shifting-baseline kernel emits itself
+    LIST_ROWS_EXTRACT = 32
+    LIST_ROWS_SHIFT = 15
+
     def tails_plan(self, dcal: DeviceCalendar, bins: BinTable, q: float, wd: int, ws: int, C: Optional[int] = None) -> Optional[int]:
-        """Number of sorted lists per (dayofyear, cell) bucket when the tail kernels take this configuration, else None
-        (bin-matrix kernels).  Results are identical on both paths (include/marex_hip.h, TAILS)."""
+        """Rows of the largest dayofyear bucket when the tail kernels take this configuration, else None (bin-matrix
+        kernels).  Results are identical on both paths (include/marex_hip.h, TAILS)."""
         if self.hobday_path == "bins":
             return None
         nd = int(np.diff(dcal.plan.doy_start).max())
@@ -236,23 +247,66 @@ class HotPath:
             return None
         if self.hobday_path != "tails" and nd < 24:
             return None  # short buckets (10-yr fields): the bin-matrix kernels are the faster ones
-        return (nd + 31) // 32
+        return nd
 
-    def tail_extract(self, anom: torch.Tensor, dcal: DeviceCalendar, bins: BinTable, wsp: Optional[dict] = None):
+    def _tail_buffers(self, nd: int, list_rows: int, Cn: int, wsp: Optional[dict]):
+        nper = (nd + list_rows - 1) // list_rows
+        nch = 2 if list_rows <= 16 else 4
+        lists = self._buf(wsp, "tails", (N_DOY, nper, nch, Cn, 8), torch.int16, self.device)
+        aux = self._buf(wsp, "tails_aux", (N_DOY, Cn), torch.int16, self.device)
+        return lists, aux
+
+    def tail_extract(self, anom: torch.Tensor, dcal: DeviceCalendar, bins: BinTable, wsp: Optional[dict] = None,
+                     list_rows: Optional[int] = None):
         """Sorted key lists of every (dayofyear, cell) bucket of ``anom`` (include/marex_hip.h, TAILS)."""
         self._bind_stream()
         T_out, Cn = anom.shape
         edges = self.bin_tables(bins)[0]
         nd = int(np.diff(dcal.plan.doy_start).max())
-        nper = (nd + 31) // 32
-        lists = self._buf(wsp, "tails", (N_DOY, nper, 4, Cn, 8), torch.int16, self.device)
-        aux = self._buf(wsp, "tails_aux", (N_DOY, Cn), torch.int16, self.device)
+        list_rows = int(list_rows or self.LIST_ROWS_EXTRACT)
+        lists, aux = self._tail_buffers(nd, list_rows, Cn, wsp)
         rc = self.lib.marex_tail_extract_f32(
             self.ctx.handle, anom.data_ptr(), T_out, Cn, dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), nd,
-            edges.data_ptr(), bins.nb, lists.data_ptr(), aux.data_ptr(),
+            edges.data_ptr(), bins.nb, list_rows, lists.data_ptr(), aux.data_ptr(),
         )
         self.ctx.check(rc, "marex_tail_extract_f32")
-        return {"tails": lists, "aux": aux, "max_bucket": nd, "_keep": edges}
+        return {"tails": lists, "aux": aux, "max_bucket": nd, "list_rows": list_rows, "_keep": edges}
+
+    def shifting_tails_ok(self, dcal: DeviceCalendar) -> bool:
+        """The anomaly kernel emits its own tails for buckets of at most 6 lists of 15 rows (option SHIFT_TAILS=0: never)."""
+        nd = int(np.diff(dcal.plan.doy_start).max())
+        return bool(self.ctx_opt("SHIFT_TAILS", 1)) and nd <= 6 * self.LIST_ROWS_SHIFT
+
+    def shifting_baseline_tails(self, x: torch.Tensor, dcal: DeviceCalendar, W: int, S: int, bins: BinTable,
+                                wsp: Optional[dict] = None) -> Dict[str, object]:
+        """Anomaly stage emitting the sorted key lists (TAILS) of its own output: no bin matrix, no extraction pass."""
+        self._bind_stream()
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+        T, Cn = x.shape
+        cal = dcal.plan
+        if cal.T != T:
+            raise ProcessingError("calendar length does not match the time axis of x")
+        if cal.has_duplicates:
+            raise ConfigurationError(
+                "shifting_baseline needs at most one timestep per (year, dayofyear)",
+                details="sub-daily time axes are not supported by the device path",
+            )
+        T_out = cal.T_out
+        out = self._buf(wsp, "anom", (T_out, Cn), torch.float32, self.device)
+        mask = self._buf(wsp, "mask", (Cn,), torch.uint8, self.device)
+        invalid = self._buf(wsp, "invalid", (Cn,), torch.int32, self.device)
+        invalid.zero_()
+        edges = self.bin_tables(bins)[0]
+        nd = int(np.diff(cal.doy_start).max())
+        lists, aux = self._tail_buffers(nd, self.LIST_ROWS_SHIFT, Cn, wsp)
+        rc = self.lib.marex_shifting_baseline_tails_f32(
+            self.ctx.handle, x.data_ptr(), T, Cn, dcal.year_plan.data_ptr(), cal.n_cal_years, int(W), int(S), edges.data_ptr(),
+            bins.nb, T_out, out.data_ptr(), mask.data_ptr(), invalid.data_ptr(), dcal.doy_start.data_ptr(),
+            dcal.doy_rows.data_ptr(), nd, lists.data_ptr(), aux.data_ptr(),
+        )
+        self.ctx.check(rc, "marex_shifting_baseline_tails_f32")
+        return {"out": out, "mask": mask, "invalid_count": invalid, "_keep": edges,
+                "tails": {"tails": lists, "aux": aux, "max_bucket": nd, "list_rows": self.LIST_ROWS_SHIFT, "_keep": edges}}
 
     def hobday_thresholds_tails(self, tl: dict, anom: torch.Tensor, dcal: DeviceCalendar, bins: BinTable, q: float, wd: int,
                                 ws: int, ny: int, nx: int, rows: Optional[tuple] = None, wsp: Optional[dict] = None):
@@ -265,9 +319,9 @@ class HotPath:
         stats[0:1].fill_(-1)
         centres = self.bin_tables(bins)[1]
         rc = self.lib.marex_hobday_thresholds_tails_f32(
-            self.ctx.handle, tl["tails"].data_ptr(), tl["aux"].data_ptr(), anom.data_ptr(), T_out, Cn, int(ny), int(nx),
-            int(tl["max_bucket"]), centres.data_ptr(), bins.nb, float(q), int(wd), int(ws), float(bins.lower_bound),
-            float(bins.upper_bound), int(row0), int(row1), thr.data_ptr(), stats.data_ptr(),
+            self.ctx.handle, tl["tails"].data_ptr(), tl["aux"].data_ptr(), int(tl["list_rows"]), anom.data_ptr(), T_out, Cn,
+            int(ny), int(nx), int(tl["max_bucket"]), centres.data_ptr(), bins.nb, float(q), int(wd), int(ws),
+            float(bins.lower_bound), float(bins.upper_bound), int(row0), int(row1), thr.data_ptr(), stats.data_ptr(),
         )
         self.ctx.check(rc, "marex_hobday_thresholds_tails_f32")
         return {"thr_doy_major": thr, "stats_dev": stats, "_keep": centres}
@@ -282,9 +336,9 @@ class HotPath:
         n_true.zero_()
         edges = self.bin_tables(bins)[0]
         rc = self.lib.marex_mask_ge_doy_tails_f32(
-            self.ctx.handle, tl["tails"].data_ptr(), tl["aux"].data_ptr(), int(tl["max_bucket"]), anom.data_ptr(), edges.data_ptr(),
-            bins.nb, thr_doy_major.data_ptr(), dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), T_out, Cn, int(c0), int(c1),
-            ext.data_ptr(), n_true.data_ptr(),
+            self.ctx.handle, tl["tails"].data_ptr(), tl["aux"].data_ptr(), int(tl["list_rows"]), int(tl["max_bucket"]),
+            anom.data_ptr(), edges.data_ptr(), bins.nb, thr_doy_major.data_ptr(), dcal.doy_start.data_ptr(),
+            dcal.doy_rows.data_ptr(), T_out, Cn, int(c0), int(c1), ext.data_ptr(), n_true.data_ptr(),
         )
         self.ctx.check(rc, "marex_mask_ge_doy_tails_f32")
         return {"extreme": ext, "n_true": n_true}
@@ -383,7 +437,10 @@ class HotPath:
         mask are produced for the owned rows only (:mod:`marex_amd.dist`).
         """
         K = self.tails_plan(dcal, bins, q, wd, ws, x.shape[1])
-        a = self.shifting_baseline(x, dcal, W, S, bins if K is None else None, wsp=workspace)
+        if K is not None and self.shifting_tails_ok(dcal):
+            a = self.shifting_baseline_tails(x, dcal, W, S, bins, wsp=workspace)
+        else:
+            a = self.shifting_baseline(x, dcal, W, S, bins if K is None else None, wsp=workspace)
         cells = None if own_rows is None else (own_rows[0] * nx, own_rows[1] * nx)
         h = self.hobday_approx(a["out"], dcal, bins, q, wd, ws, ny, nx, rows=own_rows, cells=cells, wsp=workspace,
                                binsb=a.get("bins"), tails=a.get("tails"))

@@ -28,5 +28,8 @@ def hot():
 
     _b.build(verbose=False)
     from marex_amd.detect import get_engine
+    from marex_amd.engine import HotPath
+
+    HotPath.POISON = True  # fresh output buffers start as 0xCD bytes: unwritten elements cannot pass as zeros
 
     return get_engine(0)  # the engine the public API uses: options set on it in a test reach preprocess_data too

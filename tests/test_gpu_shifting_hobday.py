@@ -138,6 +138,7 @@ def test_threshold_kernel_variants(hot):
         ("bins", {"THR_ALGO": 1, "THR_NW": 5}), ("bins", {"THR_ALGO": 1, "THR_NW": 64, "THR_U32": 1}),
         ("tails", {"THR_DD": 1}), ("tails", {"THR_DD": 5}), ("tails", {"THR_DD": 366}), ("tails", {"THR_TILE": 32}),
         ("tails", {"THR_TILE": 32, "THR_DD": 7}), ("tails", {"THR_TILE": 32, "THR_TALL": 0}),
+        ("tails", {"SHIFT_TAILS": 0}), ("tails", {"SHIFT_TAILS": 0, "THR_TILE": 32}),
     )
     for path, opts in variants:
         r = run_case(hot, "2003-01-01", 9 * 365 + 2, 19, 37, 4, 21, 11, 5, path=path, opts=opts)

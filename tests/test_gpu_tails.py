@@ -41,12 +41,12 @@ def tails_reference(anom, cal, edges):
 
 
 def device_tails_to_keys(tl, C):
-    """Device lists [366, NPER, 4, C, 8] -> (all keys of a bucket sorted descending [366, NPER*32, C], every list sorted?)."""
-    t = tl["tails"].cpu().numpy().view(np.uint16)          # [366, NPER, 4, C, 8]
-    nper = t.shape[1]
-    per_list = np.ascontiguousarray(t.transpose(0, 1, 2, 4, 3)).reshape(366, nper, 32, C)   # keys of list p in stored order
+    """Device lists [366, NPER, NCH, C, 8] -> (all keys of a bucket sorted descending [366, NPER*NCH*8, C], every list sorted?)."""
+    t = tl["tails"].cpu().numpy().view(np.uint16)          # [366, NPER, NCH, C, 8]
+    nper, nch = t.shape[1], t.shape[2]
+    per_list = np.ascontiguousarray(t.transpose(0, 1, 2, 4, 3)).reshape(366, nper, nch * 8, C)   # keys of list p in stored order
     lists_sorted = bool((np.diff(per_list.astype(np.int32), axis=2) <= 0).all())
-    allk = per_list.reshape(366, nper * 32, C)
+    allk = per_list.reshape(366, nper * nch * 8, C)
     allk = -np.sort(-allk.astype(np.int32), axis=1)
     return allk.astype(np.uint16), tl["aux"].cpu().numpy().view(np.uint16), lists_sorted
 
@@ -59,8 +59,9 @@ def make_anomalies(T_years=12, C=300, seed=3, start="2000-01-01", sigma=0.8):
     return tm, cal, anom, rng
 
 
+@pytest.mark.parametrize("list_rows", [32, 15])
 @pytest.mark.parametrize("years,C", [(12, 300), (40, 257), (3, 1024), (100, 64)])
-def test_tail_extract_matches_its_definition(hot, years, C):
+def test_tail_extract_matches_its_definition(hot, years, C, list_rows):
     tm, cal, anom, rng = make_anomalies(years, C)
     pick = rng.random(anom.shape)
     anom[pick < 0.02] = np.nan
@@ -71,7 +72,9 @@ def test_tail_extract_matches_its_definition(hot, years, C):
     anom[:, 6] = 0.25                                               # all samples in one bin: ties broken by position
     bt = binning.hobday_bins()
     dcal = hot.upload_calendar(cal)
-    tl = hot.tail_extract(torch.from_numpy(anom).to(hot.device), dcal, bt)
+    if (cal.doy_start[1:] - cal.doy_start[:-1]).max() > 6 * list_rows:
+        pytest.skip("more than 6 lists per bucket")
+    tl = hot.tail_extract(torch.from_numpy(anom).to(hot.device), dcal, bt, list_rows=list_rows)
     hot.sync()
     keys, aux, lists_sorted = device_tails_to_keys(tl, C)
     ekeys, eaux = tails_reference(anom, cal, bt.edges)
@@ -81,10 +84,10 @@ def test_tail_extract_matches_its_definition(hot, years, C):
     assert np.array_equal(keys[:, :n], ekeys) and not keys[:, n:].any()
 
 
-def _thr_case(hot, anom, cal, bt, pct, wd, ws, ny, nx, opts=None, rows=None):
+def _thr_case(hot, anom, cal, bt, pct, wd, ws, ny, nx, opts=None, rows=None, list_rows=None):
     dcal = hot.upload_calendar(cal)
     ad = torch.from_numpy(anom).to(hot.device)
-    tl = hot.tail_extract(ad, dcal, bt)
+    tl = hot.tail_extract(ad, dcal, bt, list_rows=list_rows)
     hot.ctx.debug_counters(reset=True)
     with hot.ctx.options(**(opts or {})):
         t = hot.hobday_thresholds_tails(tl, ad, dcal, bt, pct / 100.0, wd, ws or 1, ny, nx, rows=rows)
@@ -114,6 +117,8 @@ def test_low_quantiles_walk_deep_into_the_lists(hot):
     bt = binning.hobday_bins()
     _thr_case(hot, anom, cal, bt, 60.0, 11, 5, 12, 20)
     _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 12, 20)
+    _thr_case(hot, anom, cal, bt, 60.0, 11, 5, 12, 20, list_rows=15)   # the geometry the anomaly kernel emits: 3 lists of 15
+    _thr_case(hot, anom, cal, bt, 95.0, 5, 3, 12, 20, list_rows=15)
     # 100 samples per bucket: 4 lists (the largest instance of the kernels), 128 rows is the format's limit
     tm, cal, anom, rng = make_anomalies(100, 6 * 10, seed=12)
     _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 6, 10)
@@ -159,3 +164,29 @@ def test_constant_and_extreme_data(hot):
     c = _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 10, 16)
     assert c[4] > 0, c            # buckets with values beyond the table: the mask looked at the anomalies
     _thr_case(hot, anom, cal, bt, 95.0, 11, 1, 10, 16)
+
+
+@pytest.mark.parametrize("W,years,start", [(15, 100, "1925-01-01"), (5, 23, "2001-03-17"), (4, 9, "2003-01-01"), (13, 40, "1980-06-01")])
+def test_anomaly_kernel_emits_the_tails_of_its_own_output(hot, W, years, start):
+    """marex_shifting_baseline_tails_f32: same anomalies as the plain entry point, and lists holding exactly the keys the
+    extraction kernel finds in those anomalies (lists of 15 output years; mid-year starts, leap days, the 6-list limit)."""
+    tm = calendar.daily_time_axis(start, years * 365 + years // 4)
+    x = synth.synth_field(synth.make_tables(tm, 5, 29))
+    ocean = np.flatnonzero(np.isfinite(x[0]))
+    x[200:230, ocean[0]] = np.nan
+    x[:, ocean[1]] += np.float32(30.0) * (np.arange(x.shape[0]) % 11 == 0)     # values beyond the table
+    cal = calendar.build_calendar(tm, window_year_baseline=W)
+    dcal = hot.upload_calendar(cal)
+    bt = binning.hobday_bins()
+    xd = torch.from_numpy(x).to(hot.device)
+    assert hot.shifting_tails_ok(dcal)
+    a = hot.shifting_baseline_tails(xd, dcal, W, 21, bt)
+    b = hot.shifting_baseline(xd, dcal, W, 21, None)
+    hot.sync()
+    assert np.array_equal(a["out"].cpu().numpy(), b["out"].cpu().numpy(), equal_nan=True)
+    assert np.array_equal(a["invalid_count"].cpu().numpy(), b["invalid_count"].cpu().numpy())
+    k1, a1, s1 = device_tails_to_keys(a["tails"], x.shape[1])
+    ref = hot.tail_extract(a["out"], dcal, bt, list_rows=15)
+    hot.sync()
+    k2, a2, s2 = device_tails_to_keys(ref, x.shape[1])
+    assert s1 and s2 and np.array_equal(a1, a2) and np.array_equal(k1, k2)
