@@ -45,6 +45,13 @@ WORKLOADS = {
     # (314 GB of input + output do not fit 288 GB at once).  Strong scaling over N in {1,2,4,8}.
     "cfg3": dict(start="1925-01-01", T=36500, ny=720, nx=1440, W=15, S=21, wd=11, ws=5, pct=95.0, bands=8,
                  name="100yr-daily x 1440x720 (0.25deg) in 8 resident latitude bands, shifting_baseline(W=15,S=21)+hobday_extreme p95"),
+    # BASELINE.json configs[3]: 30-yr daily x 2e6-cell unstructured mesh on 4 GPUs = 500 000 cells per GPU (weak scaling),
+    # shifting_baseline + hobday_extreme p95, no spatial pooling (detect.py:1361-1385)
+    "cfg4": dict(start="1995-01-01", T=10957, ny=0, nx=500_000, W=15, S=21, wd=11, ws=1, pct=95.0,
+                 name="30yr-daily x 500000 cells per GPU of an unstructured mesh (2e6 cells on 4 GPUs), shifting_baseline(W=15,S=21)+hobday_extreme p95, no pooling"),
+    # BASELINE.json configs[4]: the 100-yr field with detrend_fixed_baseline (orders 1, 2) + hobday_extreme p90
+    "cfg5": dict(start="1925-01-01", T=36500, ny=720, nx=1440, W=None, S=21, wd=11, ws=5, pct=90.0, bands=8, detrend_orders=(1, 2),
+                 name="100yr-daily x 1440x720 (0.25deg) in 8 resident latitude bands, detrend_fixed_baseline(orders 1,2)+hobday_extreme p90"),
 }
 
 
@@ -66,12 +73,17 @@ def _cpu_worker(args):
     x = synth.synth_field(tab)
     cal = calendar.build_calendar(tm, window_year_baseline=wl["W"])
     bt = binning.hobday_bins()
+    kw = {}
+    if wl.get("detrend_orders"):
+        model, pmodel = calendar.detrend_model(calendar.decimal_year(tm), list(wl["detrend_orders"]), False)
+        kw = dict(method_anomaly="detrend_fixed_baseline", model=model, pmodel=pmodel)
+    gny, gnx, gws = (ny, nx, wl["ws"]) if wl["ny"] else (0, ny * nx, None)
     t0 = time.perf_counter()
     orc.validate_data_values(x)
     orc.preprocess_arrays(
-        x, cal, ny=ny, nx=nx, window_year_baseline=wl["W"], smooth_days_baseline=wl["S"],
-        window_days_hobday=wl["wd"], window_spatial_hobday=wl["ws"], threshold_percentile=wl["pct"],
-        edges=bt.edges, centres=bt.centres,
+        x, cal, ny=gny, nx=gnx, window_year_baseline=wl["W"] or 15, smooth_days_baseline=wl["S"],
+        window_days_hobday=wl["wd"], window_spatial_hobday=gws, threshold_percentile=wl["pct"],
+        edges=bt.edges, centres=bt.centres, **kw,
     )
     return time.perf_counter() - t0
 
@@ -102,6 +114,42 @@ def cpu_baseline(wl, seed):
     }
 
 
+def seasonal_extra(hot, shard, x, dcal, cal, step_kw, stationary_ms, amp=1.6, passes=3):
+    """AFTER the timed region: the first band again with heteroscedastic noise added (amplitude follows the day of the year,
+    so the p95 threshold of a cell swings over the year) -- the benchmark field has stationary noise, and the threshold
+    kernel's band has to FOLLOW the thresholds; this line shows what a seasonal field costs.  Overwrites `x`."""
+    import numpy as np
+    import torch
+
+    from marex_amd.dist import shard_step
+
+    T = x.shape[0]
+    g = torch.from_numpy((0.5 * (1 + np.sin(2 * np.pi * cal.doy / 365.25))).astype(np.float32)).to(hot.device)
+    gen = torch.Generator(device=hot.device).manual_seed(1)
+    for t0 in range(0, T, 2000):  # in slabs: no second field-sized temporary
+        t1 = min(T, t0 + 2000)
+        x[t0:t1] += amp * g[t0:t1, None] * torch.randn((t1 - t0, x.shape[1]), device=hot.device, generator=gen)
+    wsp = {}
+    for k in range(passes + 1):
+        if k == 1:
+            hot.sync()
+            hot.ctx.timing_reset()
+        r, _, _ = shard_step(hot, [shard], [x], dcal, workspace=wsp, **step_kw)
+    hot.sync()
+    ms = {}
+    for k in ("shifting", "tails", "thresholds", "mask"):
+        tot, n = hot.ctx.timing_get(k)
+        if n:
+            ms[k] = tot / n
+    thr = r["thr_doy_major"]  # [366, own cells]
+    ocean = torch.isfinite(thr[0])
+    swing = (thr[:, ocean].max(dim=0).values - thr[:, ocean].min(dim=0).values).median().item() if bool(ocean.any()) else 0.0
+    return {"what": f"band 0 with N(0, ({amp} * (1 + sin(2 pi doy / 365.25)) / 2)^2) added: per-launch kernel ms, {passes} passes",
+            "median_threshold_swing_K": swing, "kernel_ms": ms,
+            "thresholds_ms_stationary": stationary_ms.get("thresholds"),
+            "n_extreme": int(r["n_true"].item())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +158,7 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=20240607)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements (seasonally drifting thresholds)")
     ap.add_argument("--hobday-path", default=None, choices=["tails", "bins"],
                     help="force the representation of the dayofyear histograms (default: the engine's own choice)")
     args = ap.parse_args()
@@ -118,7 +167,7 @@ def main():
     import torch.distributed as dist
 
     from marex_amd import binning, calendar, synth
-    from marex_amd.dist import allreduce_summary, plan_shards
+    from marex_amd.dist import allreduce_step, plan_shards, shard_step
     from marex_amd.engine import HotPath
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,6 +199,9 @@ def main():
         all_shards = plan_shards(wl["ny"], nx, nbands, halo)
         shards = [all_shards[i] for i in range(rank, nbands, world)]
         ny_total = wl["ny"]
+    elif wl["ny"] == 0:  # unstructured mesh, weak scaling: wl["nx"] cells per rank of a (world * nx)-cell mesh
+        shards = [plan_shards(0, nx * world, world, 0)[rank]]
+        ny_total = 0
     else:  # weak scaling: one band of wl["ny"] rows per rank
         shards = [plan_shards(wl["ny"] * world, nx, world, halo)[rank]]
         ny_total = wl["ny"] * world
@@ -161,34 +213,25 @@ def main():
     cal = calendar.build_calendar(tm, window_year_baseline=W)
     dcal = hot.upload_calendar(cal)
     bt = binning.hobday_bins()
+    detrend = None
+    if wl.get("detrend_orders"):
+        detrend = calendar.detrend_model(calendar.decimal_year(tm), list(wl["detrend_orders"]), False)
     xs = []  # resident input, one [T, cells_in] tensor per band, generated on the device before timing
     for sh in shards:
-        tab = synth.make_tables(tm, sh.ny_in, nx, args.seed, lat_range=(sh.in0, sh.in1, sh.ny_global))
+        if sh.gridded:
+            tab = synth.make_tables(tm, sh.ny_in, nx, args.seed, lat_range=(sh.in0, sh.in1, sh.ny_global))
+        else:
+            tab = synth.make_tables(tm, 0, sh.cells_in, args.seed, unstructured=True)
         xs.append(hot.synth_field(tab, cell_base=sh.cell_base))
 
     workspace = {}  # output buffers are allocated once and reused: no allocator traffic in the timed loop
 
+    step_kw = dict(W=W or 15, S=wl["S"], bins=bt, q=wl["pct"] / 100.0, wd=wl["wd"], ws=wl["ws"], nx=nx)
+
     def step():
-        local = torch.zeros(6, dtype=torch.int64, device=hot.device)
-        mx = torch.zeros(1, dtype=torch.int64, device=hot.device)
-        r = None
-        for sh, x in zip(shards, xs):
-            own = sh.own_cell_slice()
-            r = hot.shifting_hobday(
-                x, dcal, W=W, S=wl["S"], bins=bt, q=wl["pct"] / 100.0, wd=wl["wd"], ws=wl["ws"],
-                ny=sh.ny_in, nx=nx, own_rows=(sh.own0 - sh.in0, sh.own1 - sh.in0), workspace=workspace,
-            )
-            vs = hot.validation_summary(r["mask"], r["invalid_count"], (own.start, own.stop), workspace)  # a3 verdict
-            st = r["stats_dev"]
-            local[0:3] += vs[0:3]
-            local[3:4] += r["n_true"]
-            local[4:6] += st[2:4]
-            mx = torch.maximum(mx, vs[3:4])
+        r, local, mx = shard_step(hot, shards, xs, dcal, workspace=workspace, detrend=detrend, **step_kw)
         if world > 1:
-            if backend != "nccl":  # gloo reduces host tensors
-                local, mx = local.cpu(), mx.cpu()
-            dist.all_reduce(local, op=dist.ReduceOp.SUM)
-            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            local, mx = allreduce_step(local, mx, host_collectives=backend != "nccl")
         return r, local, mx
 
     def fence():
@@ -213,14 +256,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    kern = {k: hot.ctx.timing_get(k) for k in ("shifting", "tails", "thresholds", "mask", "transpose")}
+    kern = {k: hot.ctx.timing_get(k) for k in ("shifting", "detrend", "fixed", "tails", "thresholds", "mask", "transpose")}
+    kern = {k: v for k, v in kern.items() if v[1]}
     path = r.get("path", "bins")
     summary = dict(zip(["n_ocean", "invalid_total", "invalid_cells", "n_extreme", "thr_too_low", "thr_too_high"],
                        [int(v) for v in local.tolist()]))
     summary["max_invalid"] = int(mx.item())
 
     if rank == 0:
-        C_own_total = ny_total * nx
+        C_own_total = ny_total * nx if ny_total else nx * world
         units = T * C_own_total / 1e6  # Mcells*timesteps per step, whole job
         ms_step = dt / args.steps * 1e3
         value = units / (dt / args.steps)
@@ -229,6 +273,8 @@ def main():
         b_alg_rank = algorithmic_bytes(T, T_out, cells_own_rank)
         # dominant kernel and its own algorithmic bytes PER LAUNCH (one launch = one band)
         per_kernel_alg = {
+            "detrend": shard.cells_in * (4 * T + 4 * T + 1),
+            "fixed": shard.cells_in * (4 * T + 4 * T),
             "shifting": shard.cells_in * (4 * T + 4 * T_out + 1),
             "tails": shard.cells_in * 4 * T_out,            # its compulsory read (the tails it writes are internal)
             "thresholds": shard.cells_own * 4 * 366,
@@ -239,7 +285,7 @@ def main():
         # HBM bytes of the dominant kernel from the committed PMC passes of this same command (profiles/)
         traffic = None
         tfile = os.path.join(ROOT, "profiles", f"r02_{args.workload}_traffic.json")
-        knames = {"shifting": "k_shift_fast", "tails": "k_tail_extract", "transpose": "k_transpose",
+        knames = {"shifting": "k_shift_fast", "tails": "k_tail_extract", "transpose": "k_transpose", "detrend": "k_detrend", "fixed": "k_fixed_baseline",
                   "thresholds": "k_thr_tails" if path == "tails" else "k_thr_band",
                   "mask": "k_mask_tails" if path == "tails" else "k_mask_ge"}
         kname = knames[dom]
@@ -264,12 +310,13 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": wl["name"],
-                "per_gpu_grid": [sum(sh.own1 - sh.own0 for sh in shards), nx],
-                "global_grid": [ny_total, nx],
+                "per_gpu_grid": [sum(sh.own1 - sh.own0 for sh in shards), nx] if ny_total else [sum(sh.cells_own for sh in shards)],
+                "global_grid": [ny_total, nx] if ny_total else [nx * world],
                 "bands_per_gpu": len(shards),
                 "timesteps_in": T,
                 "timesteps_out": T_out,
-                "parallelism": f"lat-band x{max(world, nbands)}, {halo} overlap rows, scalar all-reduce only",
+                "parallelism": (f"lat-band x{max(world, nbands)}, {halo} overlap rows, scalar all-reduce only" if ny_total
+                                else f"cell ranges x{world}, scalar all-reduce only"),
                 "summary": summary,
                 "histogram_representation": path,
             },
@@ -293,6 +340,8 @@ def main():
             },
             "kernel_ms": avg_ms,
         }
+        if world == 1 and not args.no_extra and detrend is None:
+            out["extra"] = {"seasonal_field": seasonal_extra(hot, shards[0], xs[0], dcal, cal, step_kw, avg_ms)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args.seed)
         print(json.dumps(out), flush=True)

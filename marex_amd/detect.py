@@ -29,16 +29,19 @@ logger = logging.getLogger("marex_amd")
 _ANOMALY_METHODS = ["detrend_harmonic", "shifting_baseline", "fixed_baseline", "detrend_fixed_baseline"]
 _EXTREME_METHODS = ["global_extreme", "hobday_extreme"]
 
-_engine_cache: Dict[int, object] = {}
+_engine_cache: Dict[object, object] = {}
 
 
-def get_engine(device: int = 0):
-    """The per-device :class:`~marex_amd.engine.HotPath` (created on first use; raises without a GPU)."""
-    if device not in _engine_cache:
+def get_engine(device: int = 0, replica: int = 0):
+    """The per-device :class:`~marex_amd.engine.HotPath` (created on first use; raises without a GPU).  ``replica`` > 0:
+    further independent engines (own context and stream) on the same device -- ``devices=[0, 0]`` drives one card from two
+    host threads."""
+    key = device if replica == 0 else (device, replica)
+    if key not in _engine_cache:
         from .engine import HotPath
 
-        _engine_cache[device] = HotPath(device)
-    return _engine_cache[device]
+        _engine_cache[key] = HotPath(device, own_stream=replica > 0)
+    return _engine_cache[key]
 
 
 # ======================================================================================
@@ -230,7 +233,7 @@ class _FieldBlock:
         return _pipe(eng).upload(f.x[:, self.c0:self.c1], np.float32)
 
 
-def plan_blocks(field: _Field, eng, halo: int, per_cell_bytes: int):
+def plan_blocks(field: _Field, eng, halo: int, per_cell_bytes: int, min_blocks: int = 1):
     """Spatial blocks that fit the free HBM -- the device-side counterpart of the reference's Dask layout for this path
     (space chunked, ``time: -1``; detect.py:2617-2620, 785-792): latitude bands with ``halo`` overlap rows per interior
     side on grids, cell ranges on meshes.  ``MAREX_BLOCKS=n`` forces the number of blocks (tests; tuning)."""
@@ -243,13 +246,13 @@ def plan_blocks(field: _Field, eng, halo: int, per_cell_bytes: int):
     ny, nx = (field.ny, field.nx) if field.gridded else (0, field.nx)
     forced = int(os.environ.get("MAREX_BLOCKS", "0"))
     if forced > 0:
-        n = min(forced, ny if field.gridded else max(nx, 1))
+        n = min(max(forced, int(min_blocks)), ny if field.gridded else max(nx, 1))
         return plan_shards(ny, nx, max(n, 1), halo)
     if eng.device.type != "cuda":
         return plan_shards(ny, nx, 1, halo)
     torch.cuda.empty_cache()
     budget = int(torch.cuda.mem_get_info(eng.device)[0] * 0.8)
-    n = 1
+    n = max(1, min(int(min_blocks), ny if field.gridded else nx))
     while True:
         shards = plan_shards(ny, nx, n, halo)
         if max(sh.cells_in for sh in shards) * per_cell_bytes <= budget:
@@ -591,8 +594,14 @@ def preprocess_data(
     verbose: Optional[bool] = None,
     quiet: Optional[bool] = None,
     device: int = 0,
+    devices: Optional[List[int]] = None,
 ):
     """Anomalies, thresholds and the boolean extreme mask of a (time, [lat,] lon / cells) field.
+
+    ``devices=[0, 1, ...]`` (extension): the field is cut into at least that many spatial blocks (latitude bands
+    with ``ws//2`` overlap rows / cell ranges -- cells are independent along time) and every listed device works through its
+    share from its own host thread; nothing is exchanged between devices, the host stitches the Dataset.  The reference fans
+    the same call out over a Dask cluster (helper.py:232-411).
 
     Mirror of ``marEx.preprocess_data`` (detect.py:287-841).  Returns a Dataset with ``dat_anomaly``
     (float32), ``mask`` (bool), ``extreme_events`` (bool), ``thresholds`` (float32, dims
@@ -635,89 +644,140 @@ def preprocess_data(
     T = field.shape[0]
     halo = (int(ws_eff) // 2) if (need_bins is not None and ws_eff) else 0
     per_cell = (4 * T + 7 * T) + (8 * T if method_anomaly.startswith("detrend") else 0) + (11 * T if want_stn else 0) + 366 * 24
-    blocks = plan_blocks(field, eng, halo, int(per_cell * 1.25))
+    dev_list = [int(d) for d in devices] if devices else [int(device)]
+    seen: Dict[int, int] = {}
+    engines = []
+    for dv in dev_list:  # the same card listed twice gets a second, independent engine (own context and stream)
+        engines.append(get_engine(dv, seen.get(dv, 0)))
+        seen[dv] = seen.get(dv, 0) + 1
+    eng = engines[0]
+    blocks = plan_blocks(field, eng, halo, int(per_cell * 1.25), min_blocks=len(engines))
     single = len(blocks) == 1
     if not single:
-        logger.info(f"Field processed in {len(blocks)} spatial blocks of <= {max(b.cells_in for b in blocks)} cells")
+        logger.info(f"Field processed in {len(blocks)} spatial blocks of <= {max(b.cells_in for b in blocks)} cells"
+                    + (f" on {len(engines)} devices" if len(engines) > 1 else ""))
+
+    import threading
 
     out: Dict[str, np.ndarray] = {}
+    out_lock = threading.Lock()
     kinds: Dict[str, str] = {}
-    defer = {"stats": [], "logged": False}
+    logged = {"logged": False}
     total = {"n_ocean": 0, "invalid_total": 0, "invalid_cells": 0, "max_invalid": 0}
     n_true_total, cal = 0, None
     doy_axis = ("dayofyear", np.arange(1, calendar.N_DOY + 1))
     C_all = field.shape[1]
 
-    def put(name, t, kind, sh):
+    def put(e, name, t, kind, sh):
         """Owned cells of a block result -> the host array of the whole field (``kind``: where the cell axis is)."""
         own = sh.own_cell_slice()
         g0 = sh.own0 * field.nx if field.gridded else sh.own0
         axis = {"cells_last": t.ndim - 1, "doy_last": 0, "doy_first": 1, "none": 0}[kind]
         view = t[(slice(None),) * axis + (own,)]
-        if name not in out:
-            shape = list(view.shape)
-            if not single:
-                shape[axis] = C_all
-            out[name] = np.empty(shape, dtype=np.dtype(str(t.dtype).replace("torch.", "")))
+        with out_lock:
+            if name not in out:
+                shape = list(view.shape)
+                if not single:
+                    shape[axis] = C_all
+                out[name] = np.empty(shape, dtype=np.dtype(str(t.dtype).replace("torch.", "")))
         dst = out[name] if single else out[name][(slice(None),) * axis + (slice(g0, g0 + view.shape[axis]),)]
         if view.dim() == 2 and axis == 1 and view.numel() * view.element_size() >= (32 << 20):
-            eng.sync()
-            _pipe(eng).download(view, dst)  # the big [T', cells] arrays: chunked through pinned buffers
+            e.sync()
+            _pipe(e).download(view, dst)  # the big [T', cells] arrays: chunked through pinned buffers
         else:
             dst[...] = view.cpu().numpy()
 
-    # the anomaly kernels emit the bin matrix only where the threshold stage will use it (engine.tails_plan: the
-    # tail kernels take most configurations and read the anomalies themselves)
-    bins_for = None
-    if need_bins is not None:
-        def bins_for(dcal, what="bins"):
-            k = eng.tails_plan(dcal, need_bins, threshold_percentile / 100.0, int(window_days_hobday), int(ws_eff) if ws_eff else 1,
-                               int(fb_cells[0]))
-            if what == "tails":
-                return need_bins if (k is not None and eng.shifting_tails_ok(dcal)) else None
-            return need_bins if k is None else None
-
-    fb_cells = [0]
-    for sh in blocks:
+    def run_block(e, sh, stop):
+        """Anomaly + threshold + mask stages of one spatial block on engine ``e``; its owned cells go to the host arrays.
+        Returns the block's validation counts, deferred warning statistics, calendar and extreme count."""
         fb = field if single else field.block(sh)
-        fb_cells[0] = fb.shape[1]
         rows = None if single or not field.gridded else (sh.own0 - sh.in0, sh.own1 - sh.in0)
-        a = _anomaly_core(eng, fb, method_anomaly, window_year_baseline, smooth_days_baseline, detrend_orders,
+        defer = {"stats": [], "logged": logged["logged"]}
+        bins_for = None
+        if need_bins is not None:
+            # the anomaly kernels emit the bin matrix only where the threshold stage will use it (engine.tails_plan: the
+            # tail kernels take long series and read the anomalies -- or the lists the anomaly kernel emits -- themselves)
+            def bins_for(dcal, what="bins"):
+                k = e.tails_plan(dcal, need_bins, threshold_percentile / 100.0, int(window_days_hobday),
+                                 int(ws_eff) if ws_eff else 1, int(fb.shape[1]))
+                if what == "tails":
+                    return need_bins if (k is not None and e.shifting_tails_ok(dcal)) else None
+                return need_bins if k is None else None
+
+        a = _anomaly_core(e, fb, method_anomaly, window_year_baseline, smooth_days_baseline, detrend_orders,
                           force_zero_mean, reference_period, bins_for)
-        cal = a["cal"]
-        part = _validation_summary(eng, a, sh.own_cell_slice())
-        for k in ("n_ocean", "invalid_total", "invalid_cells"):
-            total[k] += part[k]
-        total["max_invalid"] = max(total["max_invalid"], part["max_invalid"])
-        if total["max_invalid"] > 0 or (single and total["n_ocean"] == 0):
-            continue  # the run ends in the reference's validation error: only the counts of the other blocks matter
+        part = _validation_summary(e, a, sh.own_cell_slice())
+        res = {"part": part, "cal": a["cal"], "defer": defer, "n_true": 0, "kinds": {}}
+        if part["max_invalid"] > 0 or stop["bad"] or (single and part["n_ocean"] == 0):
+            stop["bad"] = stop["bad"] or part["max_invalid"] > 0
+            return res  # the run ends in the reference's validation error: only the counts of the other blocks matter
         ext, thr, thr_kind, n_true = _extremes_core(
-            eng, a, fb, method_extreme, threshold_percentile, window_days_hobday, ws_eff, method_percentile, bt, max_anomaly,
+            e, a, fb, method_extreme, threshold_percentile, window_days_hobday, ws_eff, method_percentile, bt, max_anomaly,
             rows=rows, defer=defer,
         )
-        put("dat_anomaly", a["anom"], "cells_last", sh)
-        put("mask", a["mask"], "cells_last", sh)
-        put("extreme_events", ext, "cells_last", sh)
-        put("thresholds", thr, thr_kind, sh)
-        kinds["thresholds"] = thr_kind
+        put(e, "dat_anomaly", a["anom"], "cells_last", sh)
+        put(e, "mask", a["mask"], "cells_last", sh)
+        put(e, "extreme_events", ext, "cells_last", sh)
+        put(e, "thresholds", thr, thr_kind, sh)
+        res["kinds"]["thresholds"] = thr_kind
         # standardised anomalies and their own extremes (detect.py:2257-2293, 686-715): detrend_harmonic only
         if want_stn:
             if sh is blocks[0]:
                 logger.info("Processing standardised anomalies for extreme identification")
-            sn = eng.std_normalise(a["anom"], a["dcal"])
-            a_stn = {"anom": sn["dat_stn"], "cal": cal, "dcal": a["dcal"], "bins": None}
+            sn = e.std_normalise(a["anom"], a["dcal"])
+            a_stn = {"anom": sn["dat_stn"], "cal": a["cal"], "dcal": a["dcal"], "bins": None}
             ext_s, thr_s, kind_s, _ = _extremes_core(
-                eng, a_stn, fb, method_extreme, threshold_percentile, window_days_hobday, ws_eff, method_percentile, bt,
+                e, a_stn, fb, method_extreme, threshold_percentile, window_days_hobday, ws_eff, method_percentile, bt,
                 max_anomaly, wsp={}, rows=rows, defer=defer,
             )
-            put("dat_stn", sn["dat_stn"], "cells_last", sh)
-            put("STD", eng.transpose(sn["STD"], name="std_cells_major"), "doy_last", sh)  # flox appends the group dim
-            put("extreme_events_stn", ext_s, "cells_last", sh)
-            put("thresholds_stn", thr_s, kind_s, sh)
-            kinds["thresholds_stn"] = kind_s
-        n_true_total += int(n_true.item()) if single else 0
-        eng.sync()
-        del a, ext, thr
+            put(e, "dat_stn", sn["dat_stn"], "cells_last", sh)
+            put(e, "STD", e.transpose(sn["STD"], name="std_cells_major"), "doy_last", sh)  # flox appends the group dim
+            put(e, "extreme_events_stn", ext_s, "cells_last", sh)
+            put(e, "thresholds_stn", thr_s, kind_s, sh)
+            res["kinds"]["thresholds_stn"] = kind_s
+        res["n_true"] = int(n_true.item()) if single else 0
+        logged["logged"] = logged["logged"] or defer["logged"]
+        e.sync()
+        return res
+
+    stop = {"bad": False}
+    results = [None] * len(blocks)
+    if len(engines) == 1:
+        for i, sh in enumerate(blocks):
+            results[i] = run_block(eng, sh, stop)
+    else:
+        import torch
+
+        def worker(k):
+            e = engines[k]
+            with torch.cuda.device(e.device), torch.cuda.stream(e.stream if e.stream is not None else torch.cuda.current_stream(e.device)):
+                for i in range(k, len(blocks), len(engines)):  # block i on device i mod N, in order
+                    results[i] = run_block(e, blocks[i], stop)
+
+        errors = []
+
+        def guarded(k):
+            try:
+                worker(k)
+            except BaseException as exc:  # re-raised in the calling thread
+                errors.append(exc)
+
+        threads = [threading.Thread(target=guarded, args=(k,)) for k in range(len(engines))]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        if errors:
+            raise errors[0]
+    defer = {"stats": []}
+    for res in results:  # block order, as a sequential run would have collected them
+        for k in ("n_ocean", "invalid_total", "invalid_cells"):
+            total[k] += res["part"][k]
+        total["max_invalid"] = max(total["max_invalid"], res["part"]["max_invalid"])
+        defer["stats"].extend(res["defer"]["stats"])
+        kinds.update(res["kinds"])
+        n_true_total += res["n_true"]
+        cal = res["cal"]
     _raise_if_invalid(field, total)
     if method_anomaly == "shifting_baseline":
         logger.info(f"Trimming data to start from {cal.min_year + window_year_baseline} (removing first {window_year_baseline} years)")

@@ -108,3 +108,76 @@ def allreduce_summary(local: Dict[str, int], device=None) -> Dict[str, int]:
         for k, v in zip(group, t.tolist()):
             out[k] = int(v)
     return out
+
+
+# --------------------------------------------------------------------------------------
+# one pass of the hot path over a rank's shards + the scalar collectives (bench.py and the tests share this code)
+# --------------------------------------------------------------------------------------
+SUMMARY_KEYS = ("n_ocean", "invalid_total", "invalid_cells", "n_extreme", "thr_too_low", "thr_too_high")
+
+
+def shard_step(hot, shards, xs, dcal, *, W: int = 15, S: int = 21, bins, q: float, wd: int, ws: int, nx: int, workspace=None,
+               detrend=None):
+    """validation + anomaly + thresholds + mask for every shard of this rank (``xs[i]`` = resident ``[T, cells_in]`` input
+    of ``shards[i]``).  ``detrend=(model, pmodel)`` switches the anomaly stage from ``shifting_baseline`` to
+    ``detrend_fixed_baseline`` (detect.py:2400-2462).  Returns ``(result of the last shard, local, mx)``: ``local`` int64[6] in
+    ``SUMMARY_KEYS`` order and ``mx`` int64[1] (largest per-cell invalid count) on the engine's device, not yet reduced
+    over ranks."""
+    import torch
+
+    local = torch.zeros(6, dtype=torch.int64, device=hot.device)
+    mx = torch.zeros(1, dtype=torch.int64, device=hot.device)
+    r = None
+    for sh, x in zip(shards, xs):
+        own = sh.own_cell_slice()
+        rows = (sh.own0 - sh.in0, sh.own1 - sh.in0) if sh.gridded else None
+        ny_s, nx_s = (sh.ny_in, nx) if sh.gridded else (0, sh.cells_in)
+        if detrend is None:
+            r = hot.shifting_hobday(x, dcal, W=W, S=S, bins=bins, q=q, wd=wd, ws=ws, ny=ny_s, nx=nx_s, own_rows=rows,
+                                    workspace=workspace)
+        else:
+            d = hot.detrend(x, detrend[0], detrend[1], True, None, count_invalid=True, wsp=workspace)
+            f = hot.fixed_baseline(d["out"], dcal, None, None, count_invalid=False, wsp=workspace)
+            h = hot.hobday_approx(f["out"], dcal, bins, q, wd, ws, ny_s, nx_s, rows=rows, cells=(own.start, own.stop), wsp=workspace)
+            r = {"dat_anomaly": f["out"], "mask": d["mask"], "invalid_count": d["invalid_count"], "thr_doy_major": h["thr_doy_major"],
+                 "stats_dev": h["stats_dev"], "extreme_events": h["extreme"], "n_true": h["n_true"], "path": h["path"]}
+        vs = hot.validation_summary(r["mask"], r["invalid_count"], (own.start, own.stop), workspace)  # a3 verdict
+        st = r["stats_dev"]
+        local[0:3] += vs[0:3]
+        local[3:4] += r["n_true"]
+        local[4:6] += st[2:4]
+        mx = torch.maximum(mx, vs[3:4])
+    return r, local, mx
+
+
+def allreduce_step(local, mx, host_collectives: bool = False):
+    """Sum / max the per-rank scalars over the process group (RCCL on GPUs; ``host_collectives``: gloo reduces host tensors)."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        if host_collectives:
+            local, mx = local.cpu(), mx.cpu()
+        dist.all_reduce(local, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    return local, mx
+
+
+def gather_owned_cells(t_local, all_shards: List[Shard], rank: int, host_collectives: bool = False):
+    """All-gather a per-shard array whose LAST axis is the rank's OWNED cells (thresholds ``[366, own]``, ``mask [own]``)
+    into the global array on every rank (optional gather of ``thresholds`` / ``mask``).  Shards may own
+    different numbers of cells: parts are padded to the largest and trimmed after the collective."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return t_local
+    world = dist.get_world_size()
+    counts = [s.cells_own for s in all_shards]
+    m = max(counts)
+    pad = torch.zeros(t_local.shape[:-1] + (m,), dtype=t_local.dtype, device=t_local.device)
+    pad[..., : counts[rank]] = t_local
+    if host_collectives:
+        pad = pad.cpu()
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad.contiguous())
+    return torch.cat([p[..., : counts[r]] for r, p in enumerate(parts)], dim=-1)

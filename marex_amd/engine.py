@@ -40,7 +40,7 @@ class DeviceCalendar:
 
 
 class HotPath:
-    def __init__(self, device: int | torch.device = 0):
+    def __init__(self, device: int | torch.device = 0, own_stream: bool = False):
         if not torch.cuda.is_available():
             raise ProcessingError(
                 "marex_amd needs a HIP device (torch.cuda.is_available() is False)",
@@ -53,6 +53,8 @@ class HotPath:
         #: None = choose per configuration (tails_plan); "tails" / "bins" force the representation of the dayofyear
         #: histograms behind the approximate Hobday thresholds (same results either way; tests use it)
         self.hobday_path: Optional[str] = None
+        #: a stream of its own (engines that share a device with another engine run under ``torch.cuda.stream(self.stream)``)
+        self.stream = torch.cuda.Stream(self.device) if own_stream else None
         self._bind_stream()
 
     #: tests set this: fresh output buffers are filled with a byte pattern, so that an element a kernel forgets to write

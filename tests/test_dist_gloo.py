@@ -35,12 +35,45 @@ def _free_port():
         return s.getsockname()[1]
 
 
+class OracleEngine:
+    """Stand-in for marex_amd.engine.HotPath on the CPU: the two methods `marex_amd.dist.shard_step` calls, computed by the
+    oracle (tests may use the oracle as the checker).  Everything around it -- shard plan, owned rows / cells, the scalar
+    all-reduce, the all-gather of thresholds -- is the code bench.py and the GPU ranks run."""
+
+    device = "cpu"
+
+    def shifting_hobday(self, x, dcal, *, W, S, bins, q, wd, ws, ny, nx, own_rows=None, workspace=None):
+        import torch
+
+        from oracle import marex_oracle as orc
+
+        xn = x.numpy()
+        r = orc.preprocess_arrays(xn, dcal, ny=ny, nx=nx, window_year_baseline=W, smooth_days_baseline=S, window_days_hobday=wd,
+                                  window_spatial_hobday=ws, threshold_percentile=q * 100.0, edges=bins.edges, centres=bins.centres)
+        own = slice(None) if own_rows is None else slice(own_rows[0] * nx, own_rows[1] * nx)
+        low = int(r["stats"]["n_too_low"]) if own_rows is None else 0  # (per-shard warning counters are not compared here)
+        return {
+            "dat_anomaly": torch.from_numpy(r["dat_anomaly"]), "mask": torch.from_numpy(r["mask"].astype(np.uint8)),
+            "invalid_count": torch.from_numpy((~np.isfinite(xn)).sum(axis=0).astype(np.int32)),
+            "thr_doy_major": torch.from_numpy(np.ascontiguousarray(r["thresholds"].T)),
+            "extreme_events": torch.from_numpy(r["extreme_events"].astype(np.uint8)),
+            "n_true": torch.tensor([int(r["extreme_events"][:, own].sum())], dtype=torch.int64),
+            "stats_dev": torch.tensor([0, 0, low, 0], dtype=torch.int32),
+        }
+
+    def validation_summary(self, mask, invalid, cells, wsp=None):
+        import torch
+
+        m = mask[cells[0]:cells[1]].numpy().astype(bool)
+        inv = np.where(m, invalid[cells[0]:cells[1]].numpy(), 0)
+        return torch.tensor([int(m.sum()), int(inv.sum()), int((inv > 0).sum()), int(inv.max()) if inv.size else 0], dtype=torch.int64)
+
+
 def _worker(rank, world, port, ny, nx, W, out_dir):
     import torch
     import torch.distributed as dist
 
-    from marex_amd.dist import allreduce_summary
-    from oracle import marex_oracle as orc
+    from marex_amd.dist import allreduce_step, gather_owned_cells, shard_step
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -48,18 +81,17 @@ def _worker(rank, world, port, ny, nx, W, out_dir):
     tm = calendar.daily_time_axis("2003-01-01", 9 * 365 + 2)
     cal = calendar.build_calendar(tm, window_year_baseline=W)
     bt = binning.hobday_bins()
-    shard = plan_shards(ny, nx, world, 2)[rank]
+    all_shards = plan_shards(ny, nx, world, 2)
+    shard = all_shards[rank]
     tab = synth.make_tables(tm, shard.ny_in, nx, lat_range=(shard.in0, shard.in1, ny))
-    x = synth.synth_field(tab, cell_base=shard.cell_base)
-    r = orc.preprocess_arrays(x, cal, ny=shard.ny_in, nx=nx, window_year_baseline=W, edges=bt.edges, centres=bt.centres)
+    x = torch.from_numpy(synth.synth_field(tab, cell_base=shard.cell_base))
+    r, local, mx = shard_step(OracleEngine(), [shard], [x], cal, W=W, S=21, bins=bt, q=0.95, wd=11, ws=5, nx=nx)
+    local, mx = allreduce_step(local, mx, host_collectives=True)
     own = shard.own_cell_slice()
-    v = orc.validate_data_values(x[:, own])
-    summ = allreduce_summary({
-        "n_ocean": v["n_ocean"], "invalid_total": v["total_invalid_in_ocean"], "invalid_max": v["max_invalid"],
-        "n_extreme": int(r["extreme_events"][:, own].sum()),
-    })
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), anom=r["dat_anomaly"], thr=r["thresholds"].T, ext=r["extreme_events"],
-             summ=np.array([summ["n_ocean"], summ["invalid_total"], summ["invalid_max"], summ["n_extreme"]]))
+    thr_all = gather_owned_cells(r["thr_doy_major"][:, own], all_shards, rank, host_collectives=True)   # [366, all cells]
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), anom=r["dat_anomaly"].numpy(), thr=r["thr_doy_major"].numpy(),
+             ext=r["extreme_events"].numpy().astype(bool), thr_all=thr_all.numpy(),
+             summ=np.array([int(local[0]), int(local[1]), int(mx[0]), int(local[3])]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,5 +113,6 @@ def test_two_rank_band_sharding_is_bit_identical(tmp_path):
     assert np.array_equal(stitch_cells([p["thr"] for p in parts], shards), ref["thresholds"].T, equal_nan=True)
     assert np.array_equal(stitch_cells([p["ext"] for p in parts], shards), ref["extreme_events"])
     v = orc.validate_data_values(x)
-    for p in parts:  # every rank holds the all-reduced scalars
+    for p in parts:  # every rank holds the all-reduced scalars and the all-gathered thresholds of the whole grid
         assert list(p["summ"]) == [v["n_ocean"], v["total_invalid_in_ocean"], v["max_invalid"], int(ref["extreme_events"].sum())]
+        assert np.array_equal(p["thr_all"], ref["thresholds"].T, equal_nan=True)
