@@ -48,6 +48,8 @@ struct marex_ctx {
     double total_ms[MAREX_K_COUNT] = {0};
     int64_t launches[MAREX_K_COUNT] = {0};
     int* shift_info = nullptr;  // device, SHIFT_INFO_WORDS ints: which dayofyear chunks the fast anomaly kernel takes
+    int* shift_plan = nullptr;  // device, [calendar years][92 chunks][8] ints: per-year records of the fast anomaly kernel
+    size_t shift_plan_years = 0;
     unsigned char* thr_scratch = nullptr;  // device, per-(tile, day, lane) state bytes of the 1024-thread threshold tiles
     size_t thr_scratch_bytes = 0;
     unsigned char* detrend_scratch = nullptr;  // device, partial sums / coefficients / means of the detrend reductions

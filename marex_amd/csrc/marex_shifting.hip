@@ -385,8 +385,13 @@ __device__ __forceinline__ void tl_out_store(tl_out_rsrc_t r, unsigned voff, uns
 #define SHIFT_INFO_WORDS 128  // [0..91] chunk handled by the fast kernel, [92] arange edges usable
 #define CLASSIFY_SPLIT 11      // threads per chunk in k_shift_classify (92 * 11 = 1012 <= 1024)
 
+// fplan[year][chunk] = two int4: {timestep of the chunk's first dayofyear (-1: absent), its output row (-1: none), number of
+// leading dayofyears present (0..4), bin-matrix row of dayofyear 0} and {bin-matrix rows of dayofyears 1..3, timestep of the
+// first dayofyear of the chunk's WORKGROUP (16 dayofyears) in the FOLLOWING year}: everything k_shift_fast needs per year
+// in ONE 32-byte scalar load, every field live (a dead field lets the register allocator recycle its SGPR and wait for
+// the load on the spot)
 __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, const float* __restrict__ edges, int nb,
-                                 int want_bins, int enable, int* __restrict__ info) {
+                                 int want_bins, int enable, int* __restrict__ info, int4* __restrict__ fplan) {
     __shared__ int s_edges_ok;
     const int t = threadIdx.x;
     int eok = 1;
@@ -425,6 +430,12 @@ __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, 
                 e[i] = (d0 + i < NDOY) ? year_plan[(size_t)y * NDOY + d0 + i] : make_int4(-1, -1, -1, 0);
             int m = 0;
             while (m < 4 && e[m].x >= 0) ++m;
+            if (fplan) {
+                const int yn = y + 1 < n_cal ? y + 1 : n_cal - 1;
+                const int tbw = year_plan[(size_t)yn * NDOY + (chunk >> 2) * 16].x;
+                fplan[((size_t)y * 92 + chunk) * 2] = make_int4(e[0].x, e[0].y, m, e[0].z);
+                fplan[((size_t)y * 92 + chunk) * 2 + 1] = make_int4(e[1].z, e[2].z, e[3].z, tbw);
+            }
             for (int i = m; i < 4; ++i) ok = ok && e[i].x < 0;
             for (int i = 1; i < m; ++i) {
                 ok = ok && e[i].x == e[0].x + i;
@@ -445,17 +456,21 @@ __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, 
 // years of the wave's 4 dayofyears wait as packed key pairs in LDS (one uniform slot per year, no per-lane counters);
 // every 16th year the wave sorts them (63 packed compare-exchanges per pair of dayofyears) and writes one list per
 // dayofyear as two 16-byte chunks per lane -- whole 1-KiB lines per wave, nothing is ever read back.
+#ifndef SHIFT_EXP
+#define SHIFT_EXP 0  // timing experiments (wrong results by design), alt builds only: 1 no barriers, 2 no row prefetch, 4 no anomaly stores, 8 no keys, 16 no smoothing sums, 32 no climatology sums
+#endif
 #define SHIFT_LIST 15   // output years per emitted list (15 x 2 pairs x 256 B x 4 waves + one 9-KiB stage = 39 KiB: 4 workgroups per CU)
 struct TailOut {
     uint4* lists;              // [366][NPER][2][C] chunks
     unsigned short* aux;       // [366][C]
     const int* doy_start;      // [367] first bin-matrix row of every dayofyear (key positions = row - doy_start)
     int nper;
+    unsigned long long* dbg;   // debug counters (-DSHIFT_STAMPS builds: phase timers)
 };
 
 template <int W, bool TAILS>
 __global__ void __launch_bounds__(256)
-k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict__ year_plan, int n_cal,
+k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict__ fplan, int n_cal,
              const int* __restrict__ info, int write_clim, const float* __restrict__ edges, int nb, long T_out, float* __restrict__ out, unsigned short* __restrict__ bins, unsigned char* __restrict__ mask,
              int* __restrict__ invalid_count, int ncg, int nblk, TailOut tails) {
     int cg, bc;
@@ -471,9 +486,16 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     constexpr int NSTAGE = TAILS ? 1 : 2;
     __shared__ float stage[NSTAGE][36 * 64];
     __shared__ unsigned newkeys[TAILS ? 4 : 1][2][TAILS ? SHIFT_LIST : 1][64];  // [wave][pair of dayofyears][year slot][lane]
+#ifdef SHIFT_PAD  // experiment: extra LDS (floats) to lower the number of resident workgroups
+    __shared__ float lds_pad[SHIFT_PAD];
+    if (T == -12345) out[0] = lds_pad[threadIdx.x];
+#endif
     const bool mine = chunk < 92 && info[chunk] != 0;  // wave-uniform; the other waves only help staging
     const int d0 = mine ? chunk * 4 : 0;
-    const int4* pblk = year_plan + bc * 16;  // first dayofyear of the workgroup (bc <= 22: always < 366)
+    // per-year records (k_shift_classify): the wave's chunk, and the workgroup's first chunk (its first timestep places the
+    // staged rows)
+    const int4* prec = fplan + (size_t)chunk * 2;  // chunk < 92: 23 workgroups of 4
+    constexpr size_t YREC = 92 * 2;  // int4 per year
     const long c = (long)cg * 64 + lane;
     const bool active = c < C;
     const unsigned cidx = active ? (unsigned)c : (unsigned)(C - 1);  // lanes beyond C duplicate the last cell
@@ -484,11 +506,12 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     const unsigned bin_lane = (((cidx >> 4) - (unsigned)(cg * 4)) * (unsigned)T_out * 16u + (cidx & 15u)) * 2u;  // bytes
     const rsrc_t rbins = make_rsrc(do_bins ? bins + (size_t)(cg * 4) * (size_t)T_out * 16 : nullptr);
 
-    float e_first = 0.f, e_delta = 1.f, inv_width = 1.f;
+    float e_first = 0.f, e_delta = 1.f, inv_width = 1.f, e_last = 0.f;
     if (do_bins || TAILS) {
         e_first = edges[1];
         e_delta = edges[2] - edges[1];
-        inv_width = (float)(nb - 1) / (edges[nb] - e_first);
+        e_last = edges[nb];
+        inv_width = (float)(nb - 1) / (e_last - e_first);
     }
     constexpr float Sf = 21.f;
     const float yS = 1.0f / Sf;
@@ -511,11 +534,12 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
 #pragma unroll
         for (int k = 0; k < 9; ++k) stage[buf & (NSTAGE - 1)][(9 * wave + k) * 64 + lane] = nx[k];
     };
-    int tb_next = pblk[0].x;
+    int tb_cur = fplan[(size_t)(bc * 4) * 2].x;
+    int tb_n1 = prec[1].w;  // year 1 (record of year 0), known one iteration ahead of its row prefetch
     {
         float nx[9];
-        if (stage_ok(tb_next)) {
-            stage_load(tb_next, nx);
+        if (stage_ok(tb_cur)) {
+            stage_load(tb_cur, nx);
             stage_store(0, nx);
         }
     }
@@ -570,29 +594,25 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
         t_slot = 0;
     };
 
-    const int4* pp = year_plan + d0;
-    const bool tail = d0 + 3 >= NDOY;  // last chunk: dayofyears 365, 366 and two that do not exist
-    const int4 absent = make_int4(-1, -1, -1, 0);
-    int4 n0 = pp[0], n1 = pp[1], n2 = tail ? absent : pp[2], n3 = tail ? absent : pp[3];
+    int4 nA = prec[0], nB = prec[1];  // year 0
+#ifdef SHIFT_STAMPS
+    unsigned long long st_top = 0, st_mid = 0, st_end = 0, st_flush = 0;
+#define SSTAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define SSTAMP(v)
+#endif
     auto one_year = [&](int y, auto Jc) {
         constexpr int J = decltype(Jc)::value;
-        const int4 p0 = n0, p1 = n1, p2 = n2, p3 = n3;
-        const int tb = tb_next;
+        SSTAMP(tsA);
+        const int4 pA = nA, pB = nB;  // {first timestep, first output row, dayofyears present, row 0}, {rows 1..3, next tb}
+        const int tb = tb_cur;
         float nx[9];
-        bool stage_next = false;
-        if (y + 1 < n_cal) {  // next year's plan and rows, one iteration ahead
-            const int4* q = pp + (size_t)(y + 1) * NDOY;
-            n0 = q[0];
-            n1 = q[1];
-            n2 = tail ? absent : q[2];
-            n3 = tail ? absent : q[3];
-            tb_next = pblk[(size_t)(y + 1) * NDOY].x;
-            stage_next = stage_ok(tb_next);
-            if (stage_next) stage_load(tb_next, nx);
-        }
+        // next year's rows, one iteration ahead (its first timestep arrived during the previous iteration)
+        const bool stage_next = y + 1 < n_cal && stage_ok(tb_n1) && !(SHIFT_EXP & 2);
+        if (stage_next) stage_load(tb_n1, nx);
         v2f smA = splat2(qnan), smB = splat2(qnan);
         v2f xp[12];  // xp[m] = rows (r0 + 2m, r0 + 2m + 1), r0 = p0.x - 10
-        const bool staged = mine && p0.x >= 0 && stage_ok(tb) && p0.x == tb + 4 * wave;
+        const bool staged = mine && pA.z > 0 && stage_ok(tb) && pA.x == tb + 4 * wave;
         if (staged) {
             const float* st = &stage[y & (NSTAGE - 1)][(4 * wave) * 64 + lane];
 #pragma unroll
@@ -604,10 +624,21 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
         if (TAILS) {
             // single stage buffer: every wave has its rows in registers before anyone overwrites the buffer with the next
             // year's (LDS traffic only: no vector-memory wait here, the row prefetch stays in flight)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!(SHIFT_EXP & 1)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        if (mine && p0.x >= 0) {
-            const long r0 = (long)p0.x - 10;
+        else asm volatile("" ::: "memory");
+        // scalar loads of the years to come go out HERE, after the wait for the staged rows: they are in flight during the
+        // arithmetic instead of in front of three dependent waits at the top of the loop
+        {
+            const int y1 = y + 1 < n_cal ? y + 1 : n_cal - 1;
+            nA = prec[(size_t)y1 * YREC];
+            nB = prec[(size_t)y1 * YREC + 1];
+            tb_cur = tb_n1;
+            tb_n1 = nB.w;  // first timestep of the workgroup in year y + 2
+        }
+        SSTAMP(tsB);
+        if (mine && pA.z > 0) {
+            const long r0 = (long)pA.x - 10;
             const bool edge = r0 < 0 || r0 + 24 > T;
             if (staged) {
             } else if (!edge) {
@@ -630,36 +661,37 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
             // smoothing: sequential sums of rows i .. i+20 for the four dayofyears i = 0..3
             v2f accA = (v2f){xp[0].x, -0.0f};
 #pragma unroll
-            for (int s = 1; s <= 20; ++s) accA = (s & 1) ? pk_add_bc_hi(accA, xp[s >> 1]) : pk_add_bc_lo(accA, xp[s >> 1]);
+            for (int s = 1; s <= ((SHIFT_EXP & 16) ? 2 : 20); ++s) accA = (s & 1) ? pk_add_bc_hi(accA, xp[s >> 1]) : pk_add_bc_lo(accA, xp[s >> 1]);
             accA.y += xp[10].y;
             v2f accB = (v2f){xp[1].x, -0.0f};
 #pragma unroll
-            for (int s = 3; s <= 22; ++s) accB = (s & 1) ? pk_add_bc_hi(accB, xp[s >> 1]) : pk_add_bc_lo(accB, xp[s >> 1]);
+            for (int s = 3; s <= ((SHIFT_EXP & 16) ? 4 : 22); ++s) accB = (s & 1) ? pk_add_bc_hi(accB, xp[s >> 1]) : pk_add_bc_lo(accB, xp[s >> 1]);
             accB.y += xp[11].y;
             smA = div_const2(accA, Sf, yS);
             smB = div_const2(accB, Sf, yS);
             if (edge) {  // windows that leave the series: NaN (a NaN row in the sum, in the general kernel)
-                const long t0 = p0.x;
+                const long t0 = pA.x;
                 smA.x = (t0 - 10 >= 0 && t0 + 10 < T) ? smA.x : qnan;
                 smA.y = (t0 - 9 >= 0 && t0 + 11 < T) ? smA.y : qnan;
                 smB.x = (t0 - 8 >= 0 && t0 + 12 < T) ? smB.x : qnan;
                 smB.y = (t0 - 7 >= 0 && t0 + 13 < T) ? smB.y : qnan;
             }
             const v2f xcA = xp[5], xcB = xp[6];
-            const bool partial = p3.x < 0;  // only a prefix of the 4 dayofyears exists this year (leap day chunk)
+            const bool partial = pA.z < 4;  // only a prefix of the 4 dayofyears exists this year (leap day chunk)
+            const bool has1 = pA.z > 1, has2 = pA.z > 2, has3 = pA.z > 3;
             if (!partial) {
                 n_invalid += (finite_f(xcA.x) ? 0 : 1) + (finite_f(xcA.y) ? 0 : 1) + (finite_f(xcB.x) ? 0 : 1) +
                              (finite_f(xcB.y) ? 0 : 1);
             } else {
                 n_invalid += finite_f(xcA.x) ? 0 : 1;
-                if (p1.x >= 0) n_invalid += finite_f(xcA.y) ? 0 : 1; else smA.y = qnan;
-                if (p2.x >= 0) n_invalid += finite_f(xcB.x) ? 0 : 1; else smB.x = qnan;
+                if (has1) n_invalid += finite_f(xcA.y) ? 0 : 1; else smA.y = qnan;
+                if (has2) n_invalid += finite_f(xcB.x) ? 0 : 1; else smB.x = qnan;
                 smB.y = qnan;
             }
-            if (p0.y >= 0) {  // output rows
+            if (pA.y >= 0) {  // output rows
                 v2f sA = splat2(0.f), sB = splat2(0.f);
 #pragma unroll
-                for (int j = 0; j < W; ++j) {
+                for (int j = 0; j < ((SHIFT_EXP & 32) ? 2 : W); ++j) {
                     sA = sA + rA[J + j];
                     sB = sB + rB[J + j];
                 }
@@ -699,12 +731,14 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                     if (!(climB.y == climB.y)) climB.y = acc[3] / (float)n[3];
                 }
                 const v2f aA = xcA - climA, aB = xcB - climB;
-                const rsrc_t ro = make_rsrc(out + (size_t)p0.y * C);
-                stb_f32(ro, voff, 0, write_clim ? climA.x : aA.x);
-                if (p1.x >= 0) stb_f32(ro, voff, rowb, write_clim ? climA.y : aA.y);
-                if (p2.x >= 0) stb_f32(ro, voff, 2 * rowb, write_clim ? climB.x : aB.x);
-                if (p3.x >= 0) stb_f32(ro, voff, 3 * rowb, write_clim ? climB.y : aB.y);
-                if (do_bins || TAILS) {
+                const rsrc_t ro = make_rsrc(out + (size_t)pA.y * C);
+                if (!(SHIFT_EXP & 4) || aA.x == 12345.678f) {
+                    stb_f32(ro, voff, 0, write_clim ? climA.x : aA.x);
+                    if (has1) stb_f32(ro, voff, rowb, write_clim ? climA.y : aA.y);
+                    if (has2) stb_f32(ro, voff, 2 * rowb, write_clim ? climB.x : aB.x);
+                    if (has3) stb_f32(ro, voff, 3 * rowb, write_clim ? climB.y : aB.y);
+                }
+                if ((do_bins || TAILS) && (!(SHIFT_EXP & 8) || aB.y == 12345.678f)) {
                     // np.digitize(a, edges) - 1 on the arange table (contract C4): the guess, biased down, is the
                     // true bin or the one below (k_shift_classify checked the error bound); one comparison with
                     // the edge above it -- recomputed with the table's own arithmetic -- settles which.  A NaN
@@ -718,38 +752,57 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                         const v2f ehi = splat2(e_first) + phi;  // edges[t + 1]
                         k0 = (int)t.x + (a.x >= ehi.x ? 1 : 0);
                         k1 = (int)t.y + (a.y >= ehi.y ? 1 : 0);
-                        k0 = (a.x == a.x) ? k0 : nb;
-                        k1 = (a.y == a.y) ? k1 : nb;
+                        if (!TAILS) {  // the keys decide "counted or not" by comparing with the last edge instead
+                            k0 = (a.x == a.x) ? k0 : nb;
+                            k1 = (a.y == a.y) ? k1 : nb;
+                        }
                     };
                     int k0, k1, k2, k3;
                     digit2(aA, k0, k1);
                     digit2(aB, k2, k3);
                     if (TAILS) {
-                        // keys of this year's 4 samples (0 for absent dayofyears and for samples the histogram drops)
-                        const bool v0 = k0 < nb, v1 = p1.x >= 0 && k1 < nb, v2 = p2.x >= 0 && k2 < nb, v3 = p3.x >= 0 && k3 < nb;
-                        const unsigned q0 = v0 ? tail_key(k0, p0.z - t_ds0) : 0u, q1 = v1 ? tail_key(k1, p1.z - t_ds1) : 0u;
-                        const unsigned q2 = v2 ? tail_key(k2, p2.z - t_ds2) : 0u, q3 = v3 ? tail_key(k3, p3.z - t_ds3) : 0u;
+                        // keys of this year's 4 samples; 0 for absent dayofyears and for samples the histogram drops: the
+                        // bin is nb exactly when a >= edges[nb], and NaN fails the comparison too
+                        const float l1 = has1 ? e_last : -__builtin_inff(), l2 = has2 ? e_last : -__builtin_inff(),
+                                    l3 = has3 ? e_last : -__builtin_inff();  // uniform
+                        const bool v0 = aA.x < e_last, v1 = aA.y < l1, v2 = aB.x < l2, v3 = aB.y < l3;
+                        // ((k + 1) << 7) | pos = (k << 7) + (128 + pos), pos < 128 uniform
+                        const unsigned b0 = 128u + (unsigned)(pA.w - t_ds0), b1 = 128u + (unsigned)(pB.x - t_ds1);
+                        const unsigned b2 = 128u + (unsigned)(pB.y - t_ds2), b3 = 128u + (unsigned)(pB.z - t_ds3);
+                        const unsigned q0 = v0 ? ((unsigned)k0 << TAIL_POS_BITS) + b0 : 0u, q1 = v1 ? ((unsigned)k1 << TAIL_POS_BITS) + b1 : 0u;
+                        const unsigned q2 = v2 ? ((unsigned)k2 << TAIL_POS_BITS) + b2 : 0u, q3 = v3 ? ((unsigned)k3 << TAIL_POS_BITS) + b3 : 0u;
                         newkeys[wave][0][t_slot][lane] = q0 | (q1 << 16);
                         newkeys[wave][1][t_slot][lane] = q2 | (q3 << 16);
-                        t_cntA += (v0 ? 1u : 0u) | (v1 ? 0x10000u : 0u);
-                        t_cntB += (v2 ? 1u : 0u) | (v3 ? 0x10000u : 0u);
-                        // not counted although it is a number: a value at or beyond the last edge
-                        t_ovfA |= ((!v0 && aA.x == aA.x) ? 1u : 0u) | ((p1.x >= 0 && !v1 && aA.y == aA.y) ? 0x10000u : 0u);
-                        t_ovfB |= ((p2.x >= 0 && !v2 && aB.x == aB.x) ? 1u : 0u) | ((p3.x >= 0 && !v3 && aB.y == aB.y) ? 0x10000u : 0u);
+                        t_cntA += (v0 ? 1u : 0u) + (v1 ? 0x10000u : 0u);
+                        t_cntB += (v2 ? 1u : 0u) + (v3 ? 0x10000u : 0u);
+                        // not counted although it is a number: a value at or beyond the last edge (next to never: one test
+                        // of the largest of the four, maxNum skips NaN)
+                        const float mx = fmaxf(fmaxf(aA.x, has1 ? aA.y : aA.x), fmaxf(has2 ? aB.x : aA.x, has3 ? aB.y : aA.x));
+                        if (__builtin_amdgcn_ballot_w64(mx >= e_last) != 0) {
+                            t_ovfA |= ((aA.x >= e_last) ? 1u : 0u) | ((has1 && aA.y >= e_last) ? 0x10000u : 0u);
+                            t_ovfB |= ((has2 && aB.x >= e_last) ? 1u : 0u) | ((has3 && aB.y >= e_last) ? 0x10000u : 0u);
+                        }
                         ++t_slot;  // flushed between years (main loop), outside this body's register pressure
                     } else {
-                        stb_u16(rbins, bin_lane, p0.z * 32, k0);
-                        if (p1.x >= 0) stb_u16(rbins, bin_lane, p1.z * 32, k1);
-                        if (p2.x >= 0) stb_u16(rbins, bin_lane, p2.z * 32, k2);
-                        if (p3.x >= 0) stb_u16(rbins, bin_lane, p3.z * 32, k3);
+                        stb_u16(rbins, bin_lane, pA.w * 32, k0);
+                        if (has1) stb_u16(rbins, bin_lane, pB.x * 32, k1);
+                        if (has2) stb_u16(rbins, bin_lane, pB.y * 32, k2);
+                        if (has3) stb_u16(rbins, bin_lane, pB.z * 32, k3);
                     }
                 }
             }
         }
         rA[J + W] = smA;  // year y joins the history
         rB[J + W] = smB;
+        SSTAMP(tsC);
         if (stage_next) stage_store((y + 1) & 1, nx);
-        __syncthreads();
+        if (!(SHIFT_EXP & 1)) __syncthreads();
+#ifdef SHIFT_STAMPS
+        const unsigned long long tsD = __builtin_amdgcn_s_memtime();
+        st_top += tsB - tsA;
+        st_mid += tsC - tsB;
+        st_end += tsD - tsC;
+#endif
     };
     for (int y = 0; y < n_cal; y += 2) {
         one_year(y, std::integral_constant<int, 0>{});
@@ -776,12 +829,21 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
         }
     }
     if (invalid_count && active && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
+#ifdef SHIFT_STAMPS
+    if (TAILS && lane == 0 && tails.dbg) {
+        atomicAdd(&tails.dbg[5], st_top);
+        atomicAdd(&tails.dbg[6], st_mid);
+        atomicAdd(&tails.dbg[7], st_end);
+        atomicAdd(&tails.dbg[4], 1ull);
+    }
+#endif
 }
 
 struct ShiftArgs {
     const float* x;
     int64_t T, C;
     const int4* year_plan;
+    const int4* fplan;
     int n_cal;
     int W, S, write_clim;
     const float* edges;
@@ -816,11 +878,11 @@ static void launch_shift_fast(marex_ctx* ctx, const ShiftArgs& a) {
     const int ncg = (int)((a.C + 63) / 64);
     if (a.tails.lists)
         hipLaunchKernelGGL((k_shift_fast<W, true>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C,
-                           a.year_plan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask,
+                           a.fplan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask,
                            a.invalid_count, ncg, 23, a.tails);
     else
         hipLaunchKernelGGL((k_shift_fast<W, false>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C,
-                           a.year_plan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask,
+                           a.fplan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask,
                            a.invalid_count, ncg, 23, a.tails);
 }
 
@@ -843,7 +905,7 @@ static int shifting_impl(marex_ctx* ctx, const char* who, const float* x, int64_
     if ((bins || tails.lists) && (!edges || nb < 4 || nb > 65534 || T_out <= 0))
         return fail(ctx, -1, "%s: binning needs edges, T_out and 4 <= nb <= 65534", who);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ShiftArgs a{x, T, C, reinterpret_cast<const int4*>(year_plan), n_cal_years, W, S, write_clim,
+    ShiftArgs a{x, T, C, reinterpret_cast<const int4*>(year_plan), nullptr, n_cal_years, W, S, write_clim,
                 edges, nb, T_out, out, bins, mask, invalid_count, nullptr, tails};
     // 4 dayofyears per workgroup (6 row loads per output) while the padded W-year LDS ring leaves room for two
     // workgroups per CU, otherwise one dayofyear
@@ -855,11 +917,22 @@ static int shifting_impl(marex_ctx* ctx, const char* who, const float* x, int64_
                           T_out < (1 << 24) && C < (1 << 24) && MAREX_ABLATE_OPT(ctx, "SHIFT_ABLATE") == 0;
     if (all_fast_possible) *all_fast_possible = fast_cfg;
     if (fast_cfg && !ctx->shift_info) HIP_TRY(ctx, hipMalloc((void**)&ctx->shift_info, SHIFT_INFO_WORDS * sizeof(int)));
+    if (fast_cfg && ctx->shift_plan_years < (size_t)n_cal_years) {
+        if (ctx->shift_plan) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // an earlier launch may still read the old table
+            (void)hipFree(ctx->shift_plan);
+            ctx->shift_plan = nullptr;
+            ctx->shift_plan_years = 0;
+        }
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->shift_plan, (size_t)n_cal_years * 92 * 8 * sizeof(int)));
+        ctx->shift_plan_years = (size_t)n_cal_years;
+    }
     LaunchTimer lt(ctx, MAREX_K_SHIFTING);  // one timed region: classify + fast kernel + general kernel
     if (fast_cfg) {
         hipLaunchKernelGGL(k_shift_classify, dim3(1), dim3(1024), 0, ctx->stream, a.year_plan, n_cal_years, edges, nb,
-                           (bins || tails.lists) ? 1 : 0, 1, ctx->shift_info);
+                           (bins || tails.lists) ? 1 : 0, 1, ctx->shift_info, reinterpret_cast<int4*>(ctx->shift_plan));
         a.skip = ctx->shift_info;
+        a.fplan = reinterpret_cast<const int4*>(ctx->shift_plan);
         switch (W) {
             case 3: launch_shift_fast<3>(ctx, a); break;
             case 4: launch_shift_fast<4>(ctx, a); break;
@@ -888,7 +961,7 @@ extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64
                                            int write_clim, const float* edges, int nb, int64_t T_out, float* out,
                                            uint16_t* bins, uint8_t* mask, int32_t* invalid_count) {
     return shifting_impl(ctx, "marex_shifting_baseline_f32", x, T, C, year_plan, n_cal_years, W, S, write_clim, edges, nb, T_out, out,
-                         bins, mask, invalid_count, TailOut{nullptr, nullptr, nullptr, 0}, nullptr);
+                         bins, mask, invalid_count, TailOut{nullptr, nullptr, nullptr, 0, nullptr}, nullptr);
 }
 
 // defined in marex_tails.hip: extraction restricted to the dayofyear chunks a flag table does NOT mark (skip == NULL: all)
@@ -906,7 +979,7 @@ extern "C" int marex_shifting_baseline_tails_f32(marex_ctx* ctx, const float* x,
         return fail(ctx, -4, "marex_shifting_baseline_tails_f32: shape outside the emitted tail format (nb <= %d, buckets <= %d rows)",
                     TAIL_MAX_NB, 6 * SHIFT_LIST);
     if (((uintptr_t)lists & 15) != 0) return fail(ctx, -1, "marex_shifting_baseline_tails_f32: lists must be 16-byte aligned");
-    TailOut t{reinterpret_cast<uint4*>(lists), aux, doy_start, (max_bucket + SHIFT_LIST - 1) / SHIFT_LIST};
+    TailOut t{reinterpret_cast<uint4*>(lists), aux, doy_start, (max_bucket + SHIFT_LIST - 1) / SHIFT_LIST, ctx_debug_counters(ctx)};
     bool fast = false;
     const int rc = shifting_impl(ctx, "marex_shifting_baseline_tails_f32", x, T, C, year_plan, n_cal_years, W, S, 0, edges, nb, T_out,
                                  out, nullptr, mask, invalid_count, t, &fast);
