@@ -30,12 +30,18 @@ __device__ __forceinline__ unsigned pk_sub_u16(unsigned a, unsigned b) {
     asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// min(x, 1) per half through the instruction itself: the compiler rewrites the generic vector min with the constant 1 into
+// (x != 0) per 16-bit element -- two compares, two selects and a permute per register instead of one v_pk_min_u16
+__device__ __forceinline__ unsigned pk_min1_u16(unsigned a) {
+    unsigned r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(0x00010001u));
+    return r;
+}
 // number of keys of a chunk that are > lim (lim replicated in both halves of lim_rep); the chunk is sorted descending, so
 // these are its FIRST keys.  10 instructions for 8 keys.
 __device__ __forceinline__ int tl_count_above(const uint4& ch, unsigned lim_rep) {
-    const unsigned one = 0x00010001u;
-    const unsigned m0 = pk_min_u16(pk_sub_sat_u16(ch.x, lim_rep), one), m1 = pk_min_u16(pk_sub_sat_u16(ch.y, lim_rep), one);
-    const unsigned m2 = pk_min_u16(pk_sub_sat_u16(ch.z, lim_rep), one), m3 = pk_min_u16(pk_sub_sat_u16(ch.w, lim_rep), one);
+    const unsigned m0 = pk_min1_u16(pk_sub_sat_u16(ch.x, lim_rep)), m1 = pk_min1_u16(pk_sub_sat_u16(ch.y, lim_rep));
+    const unsigned m2 = pk_min1_u16(pk_sub_sat_u16(ch.z, lim_rep)), m3 = pk_min1_u16(pk_sub_sat_u16(ch.w, lim_rep));
     const unsigned s = (m0 + m1) + (m2 + m3);
     return (int)((s & 0xFFFFu) + (s >> 16));
 }
@@ -765,6 +771,194 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K_T without spatial pooling (window_spatial_hobday = 1: unstructured meshes, or a gridded field asked for it): every cell
+// is on its own, so there is nothing to share between lanes -- no tiles, no halo, no barriers.  A lane owns one cell and
+// walks a block of days.  The first chunk (the 8 largest keys) of every list of the wd buckets in its window waits in a
+// per-wave LDS ring (read back only by the lane itself).
+// The quantile bin of a day is found by bisection on the bin index:
+//   iu = number of bins b with cs[b] <= qpos,  cs[b] = tot - #(samples with bin > b)           (detect.py:2510-2527)
+// a probe counts the ring's keys at or above the probe's first key, 12 instructions per list.  A first chunk gives a LOWER
+// bound of a list's count; that is enough whenever the bound already decides the comparison (a high quantile needs a handful of
+// samples of many lists), and the rare probe it does not decide -- some list with its whole first chunk at or above the probe while
+// the total is still short -- is recounted from the full lists.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_thr_cells(const uint4* __restrict__ lists, const unsigned short* __restrict__ aux, int NPER, int nch, const float* __restrict__ anom,
+            long C, long c0, long c1, int nblk, const float* __restrict__ centres, int nb, double q, int wd, float lower_bound,
+            float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats, unsigned long long* __restrict__ dbg) {
+    extern __shared__ uint4 ring[];  // [wd * NPER rounded up to a multiple of 4][64]; the padding stays zero (no keys)
+    const int lane = (int)threadIdx.x;
+    const long cell_raw = c0 + (long)blockIdx.x * 64 + lane;
+    const bool valid = cell_raw < c1;
+    const long cell = valid ? cell_raw : c1 - 1;
+    const int d_begin = (int)blockIdx.y * NDOY / nblk, d_end = ((int)blockIdx.y + 1) * NDOY / nblk;
+    const bool land = !(anom[cell] == anom[cell]);  // first kept anomaly row (detect.py:2704)
+    if (__builtin_amdgcn_ballot_w64(valid && !land) == 0) {
+        if (valid)
+            for (int d = d_begin; d < d_end; ++d) thr[(size_t)d * C + cell] = nan_f();
+        return;
+    }
+    const int pd = wd / 2, nslot = (wd * NPER + 3) & ~3;
+    uint4* mine = ring + lane;  // + slot * 64
+    for (int k = wd * NPER; k < nslot; ++k) mine[k * 64] = make_uint4(0, 0, 0, 0);
+    const unsigned voff = (unsigned)cell * 16u, chunk_row = (unsigned)C * 16u;
+    const size_t day_stride = (size_t)NPER * nch * (size_t)C;
+    auto wrap = [](int d) { return d < 0 ? d + NDOY : (d >= NDOY ? d - NDOY : d); };
+    auto cnt_of = [&](int day) { return (int)(aux[(size_t)day * C + cell] & 0x3FFu); };
+    auto load_day = [&](int day, int k) {  // bucket `day` into ring position k % wd: the first chunk of each of its lists
+        const tl_rsrc_t r = tl_make_rsrc(lists + (size_t)day * day_stride);
+        for (int p = 0; p < NPER; ++p) mine[((k % wd) * NPER + p) * 64] = tl_load_chunk(r, voff, (unsigned)(nch * p) * chunk_row);
+    };
+    int tot = 0;
+    for (int o = 0; o < wd; ++o) {
+        const int day = wrap(d_begin - pd + o);
+        load_day(day, o);
+        tot += cnt_of(day);
+    }
+    // lower bound of #(keys >= first key of bin b) from the ring
+    auto count_ring = [&](int b) {
+        const unsigned lim = ((unsigned)(b + 1) << TAIL_POS_BITS) - 1u, lim_rep = lim | (lim << 16);
+        unsigned acc0 = 0, acc1 = 0;
+        for (int k = 0; k < nslot; k += 4) {  // four lists in flight per trip
+            const uint4 c[4] = {mine[k * 64], mine[(k + 1) * 64], mine[(k + 2) * 64], mine[(k + 3) * 64]};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc0 += pk_min1_u16(pk_sub_sat_u16(c[u].x, lim_rep)) + pk_min1_u16(pk_sub_sat_u16(c[u].z, lim_rep));
+                acc1 += pk_min1_u16(pk_sub_sat_u16(c[u].y, lim_rep)) + pk_min1_u16(pk_sub_sat_u16(c[u].w, lim_rep));
+            }
+        }
+        const unsigned acc = acc0 + acc1;  // halves stay far below 65536
+        return (int)((acc & 0xFFFFu) + (acc >> 16));
+    };
+    // exact count from every chunk of every list of the window of day d (rare)
+    auto count_exact = [&](int d, int b) {
+        const unsigned lim = ((unsigned)(b + 1) << TAIL_POS_BITS) - 1u, lim_rep = lim | (lim << 16);
+        int n = 0;
+        for (int o = -pd; o <= pd; ++o) {
+            const tl_rsrc_t r = tl_make_rsrc(lists + (size_t)wrap(d + o) * day_stride);
+            for (int p = 0; p < NPER; ++p)
+                for (int jj = 0; jj < nch; ++jj) n += tl_count_above(tl_load_chunk(r, voff, (unsigned)(nch * p + jj) * chunk_row), lim_rep);
+        }
+        return n;
+    };
+    unsigned kmin = 0xFFFFFFFFu, kmax = 0u, nlow = 0u, nhigh = 0u;
+    unsigned long long n_exact = 0;
+    for (int d = d_begin; d < d_end; ++d) {
+        if (d > d_begin) {  // the window moves on: bucket d + pd takes the ring position of bucket d - pd - 1
+            const int din = wrap(d + pd), dout = wrap(d - pd - 1);
+            load_day(din, d - d_begin - 1);
+            tot += cnt_of(din) - cnt_of(dout);
+        }
+        // kfull = largest last key of a first chunk: a probe at or below it may be missing keys the ring does not hold;
+        // khead = largest key of the window: no sample lies in a bin above its bin
+        // ktail = smallest largest-key of a non-empty list: every such list has a key at or above it
+        unsigned kfull = 0, khead = 0, ktail = 0xFFFFu;
+        int nlists = 0;
+        for (int k = 0; k < nslot; k += 4) {
+            const uint4 c[4] = {mine[k * 64], mine[(k + 1) * 64], mine[(k + 2) * 64], mine[(k + 3) * 64]};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                kfull = c[u].w > kfull ? c[u].w : kfull;                                   // compares the high halves first
+                const unsigned head = c[u].x & 0xFFFFu;
+                khead = head > khead ? head : khead;
+                ktail = (head != 0u && head < ktail) ? head : ktail;
+                nlists += head != 0u ? 1 : 0;
+            }
+        }
+        kfull >>= 16;
+        float t32 = nan_f();
+        if (tot > 0) {
+            const double qpos = q * (double)tot;
+            // f(b) = cs[b] <= qpos is true below iu and false from iu on; answer in (lo, hi].  hi starts at the bin of the
+            // largest key (nothing above it: f is false there unless qpos >= tot, which the clip to nb - 1 covers).
+            // n_lo = #(bin > lo) (a lower bound unless lo_exact), n_hi = #(bin > hi) (exact)
+            int lo = -1, hi = nb - 1, n_lo = tot, n_hi = 0;
+            if (khead != 0u && (double)tot > qpos) {
+                const int bh = (int)(khead >> TAIL_POS_BITS) - 1;
+                hi = bh < hi ? bh : hi;
+            }
+            bool lo_exact = true;
+            // at least nlists samples lie in bins >= bin(ktail): if that already reaches tot - qpos, f is true below that bin
+            if (nlists > 0 && (double)(tot - nlists) <= qpos) {
+                const int bt = (int)(ktail >> TAIL_POS_BITS) - 2;  // f(bt) looks at bins > bt = bins >= bin(ktail)
+                if (bt > lo && bt < hi) {
+                    lo = bt;
+                    n_lo = nlists;
+                    lo_exact = false;
+                }
+            }
+            while (__builtin_amdgcn_ballot_w64(hi - lo > 1) != 0) {
+                const bool go = hi - lo > 1;
+                const int mid = go ? (lo + hi) >> 1 : hi;
+                int n = count_ring(mid + 1);
+                const unsigned first = (unsigned)(mid + 2) << TAIL_POS_BITS;  // first key of bin mid + 1
+                bool exact = !(first <= kfull);
+                bool f = (double)(tot - n) <= qpos;
+                if (__builtin_amdgcn_ballot_w64(go && !f && !exact) != 0) {  // the bound does not decide: count everything
+                    const int ne = count_exact(d, mid + 1);
+                    if (go && !f && !exact) {
+                        n = ne;
+                        exact = true;
+                        f = (double)(tot - n) <= qpos;
+                        ++n_exact;
+                    }
+                }
+                if (go) {
+                    if (f) {
+                        lo = mid;
+                        n_lo = n;
+                        lo_exact = exact;
+                    } else {
+                        hi = mid;
+                        n_hi = n;
+                    }
+                }
+            }
+            const int iu = hi;
+            if (__builtin_amdgcn_ballot_w64(iu > 0 && !lo_exact) != 0) {
+                const int ne = count_exact(d, iu);
+                if (iu > 0 && !lo_exact) {
+                    n_lo = ne;
+                    ++n_exact;
+                }
+            }
+            const int il = iu > 0 ? iu - 1 : 0;
+            const int cs_iu = tot - n_hi, cs_il = iu > 0 ? tot - n_lo : cs_iu;
+            const int diff = cs_iu - cs_il;
+            const double frac = diff > 0 ? (qpos - (double)cs_il) / (double)diff : 0.5;
+            const float dc = centres[iu] - centres[il];
+            const double prod = frac * (double)dc;
+            t32 = (float)((double)centres[il] + prod);
+            if (iu == 0) t32 = centres[0];
+            if (valid && !land) {
+                const unsigned key = ordered_key(t32);
+                kmin = key < kmin ? key : kmin;
+                kmax = key > kmax ? key : kmax;
+                if (t32 > upper_bound) ++nhigh;
+                if (t32 < lower_bound) ++nlow;
+            }
+            if (t32 < lower_bound) t32 = lower_bound;
+        }
+        if (valid) thr[(size_t)d * C + cell] = land ? nan_f() : t32;
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        const unsigned a = __shfl_down(kmin, sft, 64), b = __shfl_down(kmax, sft, 64);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+        nlow += __shfl_down(nlow, sft, 64);
+        nhigh += __shfl_down(nhigh, sft, 64);
+        n_exact += __shfl_down(n_exact, sft, 64);
+    }
+    if (lane == 0) {
+        if (kmin != 0xFFFFFFFFu) atomicMin(&stats->min_key, kmin);
+        if (kmax != 0u) atomicMax(&stats->max_key, kmax);
+        if (nlow) atomicAdd(&stats->n_too_low, nlow);
+        if (nhigh) atomicAdd(&stats->n_too_high, nhigh);
+        if (dbg && n_exact) atomicAdd(&dbg[1], n_exact);
+    }
+}
+
 extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, int list_rows,
                                                  const float* anom, int64_t T_out, int64_t C, int ny, int nx, int max_bucket,
                                                  const float* centres,
@@ -794,7 +988,24 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
                              "ws <= 7, pooled window <= 65535 samples)", TAIL_MAX_NB, TAIL_MAX_BUCKET);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int NPER, nch;
-    if (!tails_geometry(max_bucket, list_rows, NPER, nch) || NPER > 6)
+    if (!tails_geometry(max_bucket, list_rows, NPER, nch))
+        return fail(ctx, -4, "marex_hobday_thresholds_tails_f32: %d rows per bucket in lists of %d", max_bucket, list_rows);
+    if (p == 0 && wd * NPER <= 128 && ctx_opt(ctx, "THR_CELLS", 1)) {  // no spatial pooling: one lane per cell, no tiles
+        const long c0 = ny > 0 ? (long)row0 * nx : 0, c1 = ny > 0 ? (long)row1 * nx : (long)C;
+        const long ncg = (c1 - c0 + 63) / 64;
+        int nblk = (int)((32L * 4 * device_cus(ctx) + ncg - 1) / ncg);  // several rounds of waves (an even finish); every block re-reads wd - 1 buckets
+        nblk = nblk < 1 ? 1 : (nblk > 12 ? 12 : nblk);
+        nblk = ctx_opt(ctx, "THR_CELLS_BLOCKS", nblk);
+        LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
+        const size_t lds = (size_t)((wd * NPER + 3) & ~3) * 64 * sizeof(uint4);
+        if (lds > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_thr_cells, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_thr_cells, dim3((unsigned)ncg, (unsigned)nblk), dim3(64), lds, ctx->stream,
+                           reinterpret_cast<const uint4*>(lists), aux, NPER, nch, anom, (long)C, c0, c1, nblk, centres, nb, q, wd,
+                           lower_bound, upper_bound, thr_doy_major, stats, ctx_debug_counters(ctx));
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    }
+    if (NPER > 6)
         return fail(ctx, -4, "marex_hobday_thresholds_tails_f32: %d rows per bucket in lists of %d: more than 6 lists", max_bucket, list_rows);
     const int tile_pref = ctx_opt(ctx, "THR_TILE", (ny > 0 && p > 0 && max_bucket >= 24) ? 32 : 16);
     const bool big = (ny > 0 && p > 0) && tile_pref == 32 && (row1 - row0) >= 16 && nx >= 16;

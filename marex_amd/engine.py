@@ -247,9 +247,9 @@ class HotPath:
         nd = int(np.diff(dcal.plan.doy_start).max())
         if not (bins.nb <= 511 and 1 <= nd <= 128 and ws <= 7 and nd * wd * ws * ws <= 65535 and (C is None or C <= (1 << 24))):
             return None
-        if self.hobday_path != "tails" and nd < 24:
-            return None  # short buckets (10-yr fields): the bin-matrix kernels are the faster ones
-        return nd
+        if self.hobday_path != "tails" and nd < 24 and ws > 1:
+            return None  # short buckets with spatial pooling (cfg2): the bin-matrix kernels are the faster ones
+        return nd  # ws == 1: the per-cell threshold kernel (no tiles), any record length
 
     def _tail_buffers(self, nd: int, list_rows: int, Cn: int, wsp: Optional[dict]):
         nper = (nd + list_rows - 1) // list_rows

@@ -190,3 +190,24 @@ def test_anomaly_kernel_emits_the_tails_of_its_own_output(hot, W, years, start):
     hot.sync()
     k2, a2, s2 = device_tails_to_keys(ref, x.shape[1])
     assert s1 and s2 and np.array_equal(a1, a2) and np.array_equal(k1, k2)
+
+
+@pytest.mark.parametrize("years,pct,wd,list_rows", [(15, 95.0, 11, 15), (30, 95.0, 11, 15), (5, 90.0, 5, 15), (40, 95.0, 31, 32),
+                                                     (85, 99.0, 11, 15), (22, 60.0, 11, 32), (22, 100.0, 3, 15)])
+def test_per_cell_threshold_kernel_without_spatial_pooling(hot, years, pct, wd, list_rows):
+    """window_spatial_hobday = 1 (unstructured meshes): one lane per cell, bisection on the bin index over the first chunks of
+    the window's lists.  Short and long records, both list geometries, wide day windows, q = 0.6 (bounds from first chunks do
+    not decide every probe: the exact recount runs) and q = 1."""
+    tm, cal, anom, rng = make_anomalies(years, 333, seed=years)
+    anom[:, 5] = np.nan
+    anom[: anom.shape[0] // 2, 6] = np.nan           # half a record: fewer samples, other totals than its neighbours
+    anom[:, 7] = np.float32(0.25)                     # ties: every sample in one bin
+    anom[:, 8] = np.float32(7.0)                      # nothing countable
+    bt = binning.hobday_bins()
+    c = _thr_case(hot, anom, cal, bt, pct, wd, None, 0, 333, list_rows=list_rows)
+    if pct == 60.0:
+        assert c[1] > 0, c                            # probes the first chunks could not decide
+    c0 = _thr_case(hot, anom, cal, bt, pct, wd, None, 0, 333, list_rows=list_rows, opts={"THR_CELLS": 0})  # the tile kernel, same bits
+    assert c0[1] == 0
+    if years <= 30:  # gridded field asked for ws = 1, owned rows only, several day blocks
+        _thr_case(hot, anom[:, :330].copy(), cal, bt, pct, wd, 1, 11, 30, rows=(2, 9), list_rows=list_rows, opts={"THR_CELLS_BLOCKS": 5})
