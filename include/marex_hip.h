@@ -215,6 +215,12 @@ int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, const uint16_
 int marex_fixed_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* doy_start,
                              const int32_t* doy_rows, const uint8_t* use_row, const float* edges, int nb,
                              float* out, uint16_t* bins, uint8_t* mask, int32_t* invalid_count);
+/* The same stage with a per-cell value `sub[C]` taken off every sample on load (one float32 subtraction, as
+ * detect.py:2222-2224 does for the whole field): folds the last pass of a force_zero_mean detrend into this one. */
+int marex_fixed_baseline_sub_f32(marex_ctx* ctx, const float* x, const float* sub, int64_t T, int64_t C,
+                                 const int32_t* doy_start, const int32_t* doy_rows, const uint8_t* use_row,
+                                 const float* edges, int nb, float* out, uint16_t* bins, uint8_t* mask,
+                                 int32_t* invalid_count);
 
 /* bins[rowb_index[t], c] = np.digitize(anom[t, c], edges) - 1 for rows with rowb_index[t] >= 0 (detect.py:2622-2631) */
 int marex_digitize_f32(marex_ctx* ctx, const float* anom, int64_t T, int64_t C, const int32_t* rowb_index,
@@ -231,6 +237,11 @@ int marex_digitize_f32(marex_ctx* ctx, const float* anom, int64_t T, int64_t C, 
 int marex_detrend_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
                       const double* model_t, int n_coef, int force_zero_mean, float* out, uint8_t* mask,
                       int32_t* invalid_count);
+/* detect.py:2143-2224 with force_zero_mean, the mean NOT yet subtracted: `out` = residuals, `mean[C]` = fl32(sum / T)
+ * (the value marex_detrend_f32 would subtract); for callers that subtract while reading (marex_fixed_baseline_sub_f32). */
+int marex_detrend_deferred_mean_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
+                                    const double* model_t, int n_coef, float* out, float* mean, uint8_t* mask,
+                                    int32_t* invalid_count);
 
 /*
  * Exact Hobday percentile (detect.py:1921-1956): thr[d, c] = np.nanpercentile(anom[doy in window(d), c], p),

@@ -12,7 +12,7 @@ k_fixed_baseline(const float* __restrict__ x, long T, long C, const int* __restr
                  const int* __restrict__ doy_rows, const unsigned char* __restrict__ use_row,
                  const float* __restrict__ edges, int nb, float* __restrict__ out,
                  unsigned short* __restrict__ bins, unsigned char* __restrict__ mask,
-                 int* __restrict__ invalid_count) {
+                 int* __restrict__ invalid_count, const float* __restrict__ sub) {
     extern __shared__ float e[];
     const int d = blockIdx.y;
     const long c = (long)blockIdx.x * 256 + threadIdx.x;
@@ -25,11 +25,16 @@ k_fixed_baseline(const float* __restrict__ x, long T, long C, const int* __restr
     const float inv_width = do_bins ? (float)(nb - 1) / (e[nb] - e[1]) : 0.f;
     if (d == 0 && mask) mask[c] = finite_f(x[c]) ? 1 : 0;
     const int r0 = doy_start[d], r1 = doy_start[d + 1];
+    // sub: a per-cell value taken off every sample on load (the residual mean of a detrend whose last pass -- subtracting
+    // it from the whole field -- is folded in here: the same single float32 subtraction, one round trip through HBM less)
+    const bool has_sub = sub != nullptr;
+    const float sc = has_sub ? sub[c] : 0.f;
     float acc = 0.f;
     int n = 0, n_invalid = 0;
     for (int r = r0; r < r1; ++r) {
         const int t = doy_rows[r];
-        const float v = x[(size_t)t * C + c];
+        float v = x[(size_t)t * C + c];
+        if (has_sub) v -= sc;
         if (!finite_f(v)) ++n_invalid;
         if ((!use_row || use_row[t]) && v == v) {
             acc += v;
@@ -39,17 +44,37 @@ k_fixed_baseline(const float* __restrict__ x, long T, long C, const int* __restr
     const float clim = acc / (float)n;  // n == 0 -> NaN
     for (int r = r0; r < r1; ++r) {
         const int t = doy_rows[r];
-        const float a = x[(size_t)t * C + c] - clim;
+        float v = x[(size_t)t * C + c];
+        if (has_sub) v -= sc;
+        const float a = v - clim;
         out[(size_t)t * C + c] = a;
         if (do_bins) bins[bins_index(r, c, T)] = (unsigned short)digitize_bin(a, e, nb, inv_width);
     }
     if (invalid_count && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
 }
 
+static int fixed_baseline_impl(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* doy_start,
+                               const int32_t* doy_rows, const uint8_t* use_row, const float* edges, int nb, float* out,
+                               uint16_t* bins, uint8_t* mask, int32_t* invalid_count, const float* sub);
+
 extern "C" int marex_fixed_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C,
                                         const int32_t* doy_start, const int32_t* doy_rows,
                                         const uint8_t* use_row, const float* edges, int nb, float* out,
                                         uint16_t* bins, uint8_t* mask, int32_t* invalid_count) {
+    return fixed_baseline_impl(ctx, x, T, C, doy_start, doy_rows, use_row, edges, nb, out, bins, mask, invalid_count, nullptr);
+}
+
+extern "C" int marex_fixed_baseline_sub_f32(marex_ctx* ctx, const float* x, const float* sub, int64_t T, int64_t C,
+                                            const int32_t* doy_start, const int32_t* doy_rows, const uint8_t* use_row,
+                                            const float* edges, int nb, float* out, uint16_t* bins, uint8_t* mask,
+                                            int32_t* invalid_count) {
+    if (ctx && !sub) return fail(ctx, -1, "marex_fixed_baseline_sub_f32: null pointer");
+    return fixed_baseline_impl(ctx, x, T, C, doy_start, doy_rows, use_row, edges, nb, out, bins, mask, invalid_count, sub);
+}
+
+static int fixed_baseline_impl(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* doy_start,
+                               const int32_t* doy_rows, const uint8_t* use_row, const float* edges, int nb, float* out,
+                               uint16_t* bins, uint8_t* mask, int32_t* invalid_count, const float* sub) {
     if (!ctx) return -1;
     if (!x || !doy_start || !doy_rows || !out || T <= 0 || C <= 0)
         return fail(ctx, -1, "marex_fixed_baseline_f32: null pointer or empty shape");
@@ -62,7 +87,7 @@ extern "C" int marex_fixed_baseline_f32(marex_ctx* ctx, const float* x, int64_t 
     {
         LaunchTimer lt(ctx, MAREX_K_FIXED);
         hipLaunchKernelGGL(k_fixed_baseline, grid, dim3(256), lds, ctx->stream, x, (long)T, (long)C, doy_start, doy_rows,
-                           use_row, edges, nb, out, bins, mask, invalid_count);
+                           use_row, edges, nb, out, bins, mask, invalid_count, sub);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -217,9 +242,24 @@ k_detrend_sub(long T, long C, const float* __restrict__ mean, float* __restrict_
     }
 }
 
+static int detrend_impl(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel, const double* model_t,
+                        int n_coef, int force_zero_mean, float* out, uint8_t* mask, int32_t* invalid_count, float* mean_out);
+
 extern "C" int marex_detrend_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
                                  const double* model_t, int n_coef, int force_zero_mean, float* out, uint8_t* mask,
                                  int32_t* invalid_count) {
+    return detrend_impl(ctx, x, T, C, pmodel, model_t, n_coef, force_zero_mean, out, mask, invalid_count, nullptr);
+}
+
+extern "C" int marex_detrend_deferred_mean_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
+                                               const double* model_t, int n_coef, float* out, float* mean, uint8_t* mask,
+                                               int32_t* invalid_count) {
+    if (ctx && !mean) return fail(ctx, -1, "marex_detrend_deferred_mean_f32: null pointer");
+    return detrend_impl(ctx, x, T, C, pmodel, model_t, n_coef, 1, out, mask, invalid_count, mean);
+}
+
+static int detrend_impl(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel, const double* model_t,
+                        int n_coef, int force_zero_mean, float* out, uint8_t* mask, int32_t* invalid_count, float* mean_out) {
     if (!ctx) return -1;
     if (!x || !pmodel || !model_t || !out || T <= 0 || C <= 0) return fail(ctx, -1, "marex_detrend_f32: null pointer or empty shape");
     if (n_coef < 1 || n_coef > DETREND_MAXC) return fail(ctx, -4, "marex_detrend_f32: n_coef must be in 1..%d", DETREND_MAXC);
@@ -247,7 +287,9 @@ extern "C" int marex_detrend_f32(marex_ctx* ctx, const float* x, int64_t T, int6
                            mask);
         hipLaunchKernelGGL(k_detrend_resid, dim3(ncb, ntb), dim3(256), 0, ctx->stream, x, (long)T, (long)C, model_t, n_coef,
                            coef, out, partial);
-        if (force_zero_mean) {
+        if (force_zero_mean && mean_out) {  // the caller subtracts (marex_fixed_baseline_sub_f32 does it on load)
+            hipLaunchKernelGGL(k_detrend_mean, dim3(ncb), dim3(256), 0, ctx->stream, (long)T, (long)C, ntb, partial, mean_out);
+        } else if (force_zero_mean) {
             hipLaunchKernelGGL(k_detrend_mean, dim3(ncb), dim3(256), 0, ctx->stream, (long)T, (long)C, ntb, partial, mean);
             hipLaunchKernelGGL(k_detrend_sub, dim3((unsigned)((C / 4 + 256) / 256), (unsigned)((T + 63) / 64)), dim3(256), 0,
                                ctx->stream, (long)T, (long)C, mean, out);

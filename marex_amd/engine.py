@@ -470,8 +470,10 @@ class HotPath:
         bins: Optional[BinTable] = None,
         count_invalid: bool = True,
         wsp: Optional[dict] = None,
+        sub: Optional[torch.Tensor] = None,
     ) -> Dict[str, torch.Tensor]:
-        """``x - nanmean_doy(x)`` for all timesteps (detect.py:2299-2397); ``dcal`` must be an untrimmed calendar."""
+        """``x - nanmean_doy(x)`` for all timesteps (detect.py:2299-2397); ``dcal`` must be an untrimmed calendar.
+        ``sub`` ``[C]``: a per-cell value taken off ``x`` on load (the deferred residual mean of :meth:`detrend`)."""
         self._bind_stream()
         T, Cn = x.shape
         cal = dcal.plan
@@ -489,11 +491,13 @@ class HotPath:
             e_ptr, b_ptr, nb = edges.data_ptr(), binsb.data_ptr(), bins.nb
         else:
             binsb, e_ptr, b_ptr, nb = None, None, None, 0
-        rc = self.lib.marex_fixed_baseline_f32(
-            self.ctx.handle, x.data_ptr(), T, Cn, dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(),
-            use.data_ptr() if use is not None else None, e_ptr, nb, out.data_ptr(), b_ptr,
-            mask.data_ptr(), invalid.data_ptr() if count_invalid else None,
-        )
+        tail = (T, Cn, dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), use.data_ptr() if use is not None else None, e_ptr, nb,
+                out.data_ptr(), b_ptr, mask.data_ptr(), invalid.data_ptr() if count_invalid else None)
+        if sub is None:
+            rc = self.lib.marex_fixed_baseline_f32(self.ctx.handle, x.data_ptr(), *tail)
+        else:
+            assert sub.dtype == torch.float32 and sub.numel() == Cn
+            rc = self.lib.marex_fixed_baseline_sub_f32(self.ctx.handle, x.data_ptr(), sub.data_ptr(), *tail)
         self.ctx.check(rc, "marex_fixed_baseline_f32")
         if use is not None:
             self.sync()  # the small table must outlive the kernel
@@ -526,8 +530,11 @@ class HotPath:
         bins_and_cal=None,
         count_invalid: bool = True,
         wsp: Optional[dict] = None,
+        defer_mean: bool = False,
     ) -> Dict[str, torch.Tensor]:
-        """Residual of the least-squares fit of ``model`` (detect.py:2143-2224); optional binning of the result."""
+        """Residual of the least-squares fit of ``model`` (detect.py:2143-2224); optional binning of the result.
+        ``defer_mean`` (with ``force_zero_mean``): ``out`` keeps its mean and ``res["mean"]`` ``[C]`` is the value still to be
+        subtracted -- :meth:`fixed_baseline` takes it as ``sub`` and saves a pass over the field."""
         self._bind_stream()
         T, Cn = x.shape
         n_coef = int(model.shape[0])
@@ -536,13 +543,23 @@ class HotPath:
         out = self._buf(wsp, "detrended", (T, Cn), torch.float32, self.device)
         mask = self._buf(wsp, "mask", (Cn,), torch.uint8, self.device)
         invalid = self._buf(wsp, "invalid", (Cn,), torch.int32, self.device)
-        rc = self.lib.marex_detrend_f32(
-            self.ctx.handle, x.data_ptr(), T, Cn, pm.data_ptr(), mt.data_ptr(), n_coef, int(bool(force_zero_mean)),
-            out.data_ptr(), mask.data_ptr(), invalid.data_ptr(),
-        )
+        mean = None
+        if defer_mean and force_zero_mean:
+            mean = self._buf(wsp, "detrend_mean", (Cn,), torch.float32, self.device)
+            rc = self.lib.marex_detrend_deferred_mean_f32(
+                self.ctx.handle, x.data_ptr(), T, Cn, pm.data_ptr(), mt.data_ptr(), n_coef, out.data_ptr(), mean.data_ptr(),
+                mask.data_ptr(), invalid.data_ptr(),
+            )
+        else:
+            rc = self.lib.marex_detrend_f32(
+                self.ctx.handle, x.data_ptr(), T, Cn, pm.data_ptr(), mt.data_ptr(), n_coef, int(bool(force_zero_mean)),
+                out.data_ptr(), mask.data_ptr(), invalid.data_ptr(),
+            )
         self.ctx.check(rc, "marex_detrend_f32")
         self.sync()  # pm / mt must outlive the kernel
         res = {"out": out, "mask": mask, "invalid_count": invalid}
+        if mean is not None:
+            res["mean"] = mean
         if bins_and_cal is not None and bins_and_cal[0] is not None:
             res["bins"] = self.digitize(out, bins_and_cal[1], bins_and_cal[0], wsp=wsp)
         return res

@@ -27,7 +27,7 @@ if amp > 0:
         x[t0:t1] += amp * g[t0:t1, None] * torch.randn((t1 - t0, ny * nx), device=hot.device, generator=gen)
 ws = {}
 for dd in os.environ.get("DDS", "0,32,48,61,0").split(","):
-    os.environ["MAREX_THR_DD"] = dd
+    hot.ctx.set_option("THR_DD", int(dd))  # options are read from the context, not from the environment at launch
     for k in range(3):
         if k == 1:
             hot.sync()
