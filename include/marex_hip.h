@@ -215,9 +215,11 @@ int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, const uint16_
 int marex_fixed_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* doy_start,
                              const int32_t* doy_rows, const uint8_t* use_row, const float* edges, int nb,
                              float* out, uint16_t* bins, uint8_t* mask, int32_t* invalid_count);
-/* The same stage with a per-cell value `sub[C]` taken off every sample on load (one float32 subtraction, as
- * detect.py:2222-2224 does for the whole field): folds the last pass of a force_zero_mean detrend into this one. */
-int marex_fixed_baseline_sub_f32(marex_ctx* ctx, const float* x, const float* sub, int64_t T, int64_t C,
+/* The same stage with an optional per-cell value `sub[C]` taken off every sample on load (one float32 subtraction, as
+ * detect.py:2222-2224 does for the whole field): folds the last pass of a force_zero_mean detrend into this one.
+ * `max_bucket` = rows of the largest dayofyear bucket (0 = unknown): up to 128 rows without a bin matrix the field is read
+ * once (buckets held in registers). */
+int marex_fixed_baseline_sub_f32(marex_ctx* ctx, const float* x, const float* sub, int max_bucket, int64_t T, int64_t C,
                                  const int32_t* doy_start, const int32_t* doy_rows, const uint8_t* use_row,
                                  const float* edges, int nb, float* out, uint16_t* bins, uint8_t* mask,
                                  int32_t* invalid_count);

@@ -468,7 +468,7 @@ struct TailOut {
     unsigned long long* dbg;   // debug counters (-DSHIFT_STAMPS builds: phase timers)
 };
 
-template <int W, bool TAILS>
+template <int W, bool TAILS, int S = 21>
 __global__ void __launch_bounds__(256)
 k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict__ fplan, int n_cal,
              const int* __restrict__ info, int write_clim, const float* __restrict__ edges, int nb, long T_out, float* __restrict__ out, unsigned short* __restrict__ bins, unsigned char* __restrict__ mask,
@@ -483,8 +483,11 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     // 24 from there -- 2.25 instead of 6 row reads per output row leave the L2.
     // TAILS: ONE stage buffer (a second barrier per year separates its readers from the next year's writers) so that the
     // waiting keys fit beside it at four workgroups per CU
+    // smoothing width S (odd): a wave needs S + 3 rows for its 4 dayofyears, the workgroup S + 15, H = S / 2 before the first
+    static_assert((S & 1) == 1 && S >= 5 && S <= 25, "k_shift_fast: odd smoothing widths 5..25");
+    constexpr int H = S / 2, NPAIR = (S + 3) / 2, NST = S + 15, RPW = (NST + 3) / 4;  // RPW: rows each wave stages per year
     constexpr int NSTAGE = TAILS ? 1 : 2;
-    __shared__ float stage[NSTAGE][36 * 64];
+    __shared__ float stage[NSTAGE][NST * 64];
     __shared__ unsigned newkeys[TAILS ? 4 : 1][2][TAILS ? SHIFT_LIST : 1][64];  // [wave][pair of dayofyears][year slot][lane]
 #ifdef SHIFT_PAD  // experiment: extra LDS (floats) to lower the number of resident workgroups
     __shared__ float lds_pad[SHIFT_PAD];
@@ -513,7 +516,7 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
         e_last = edges[nb];
         inv_width = (float)(nb - 1) / (e_last - e_first);
     }
-    constexpr float Sf = 21.f;
+    constexpr float Sf = (float)S;
     const float yS = 1.0f / Sf;
     const float Wf = (float)W;
     const float yW = 1.0f / Wf;
@@ -522,22 +525,24 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     const float qnan = nan_f();
 
     if (chunk == 0 && mine && mask && active) mask[c] = finite_f(x[c]) ? 1 : 0;
-    // rows tb-10 .. tb+25 (tb = timestep of the workgroup's first dayofyear in that year) can be staged when they
-    // all lie inside the series; this wave loads rows 9*wave .. 9*wave+8 of them
-    auto stage_ok = [&](int tb) { return tb >= 10 && (long)tb + 26 <= T; };
-    auto stage_load = [&](int tb, float (&nx)[9]) {
-        const rsrc_t rs = make_rsrc(x + (size_t)(tb - 10 + 9 * wave) * C);
+    // rows tb-H .. tb+15+H (tb = timestep of the workgroup's first dayofyear in that year) can be staged when they
+    // all lie inside the series; this wave loads rows RPW*wave .. RPW*wave+RPW-1 of them (the last wave fewer when 4 RPW > NST)
+    auto stage_ok = [&](int tb) { return tb >= H && (long)tb + 16 + H <= T; };
+    auto stage_load = [&](int tb, float (&nx)[RPW]) {
+        const rsrc_t rs = make_rsrc(x + (size_t)(tb - H + RPW * wave) * C);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) nx[k] = ldb_f32(rs, voff, k * rowb);
+        for (int k = 0; k < RPW; ++k)
+            if (4 * RPW == NST || RPW * wave + k < NST) nx[k] = ldb_f32(rs, voff, k * rowb);
     };
-    auto stage_store = [&](int buf, const float (&nx)[9]) {
+    auto stage_store = [&](int buf, const float (&nx)[RPW]) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) stage[buf & (NSTAGE - 1)][(9 * wave + k) * 64 + lane] = nx[k];
+        for (int k = 0; k < RPW; ++k)
+            if (4 * RPW == NST || RPW * wave + k < NST) stage[buf & (NSTAGE - 1)][(RPW * wave + k) * 64 + lane] = nx[k];
     };
     int tb_cur = fplan[(size_t)(bc * 4) * 2].x;
     int tb_n1 = prec[1].w;  // year 1 (record of year 0), known one iteration ahead of its row prefetch
     {
-        float nx[9];
+        float nx[RPW];
         if (stage_ok(tb_cur)) {
             stage_load(tb_cur, nx);
             stage_store(0, nx);
@@ -606,17 +611,17 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
         SSTAMP(tsA);
         const int4 pA = nA, pB = nB;  // {first timestep, first output row, dayofyears present, row 0}, {rows 1..3, next tb}
         const int tb = tb_cur;
-        float nx[9];
+        float nx[RPW];
         // next year's rows, one iteration ahead (its first timestep arrived during the previous iteration)
         const bool stage_next = y + 1 < n_cal && stage_ok(tb_n1) && !(SHIFT_EXP & 2);
         if (stage_next) stage_load(tb_n1, nx);
         v2f smA = splat2(qnan), smB = splat2(qnan);
-        v2f xp[12];  // xp[m] = rows (r0 + 2m, r0 + 2m + 1), r0 = p0.x - 10
+        v2f xp[NPAIR];  // xp[m] = rows (r0 + 2m, r0 + 2m + 1), r0 = first timestep - H
         const bool staged = mine && pA.z > 0 && stage_ok(tb) && pA.x == tb + 4 * wave;
         if (staged) {
             const float* st = &stage[y & (NSTAGE - 1)][(4 * wave) * 64 + lane];
 #pragma unroll
-            for (int m = 0; m < 12; ++m) {
+            for (int m = 0; m < NPAIR; ++m) {
                 xp[m].x = st[(2 * m) * 64];
                 xp[m].y = st[(2 * m + 1) * 64];
             }
@@ -638,19 +643,19 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
         }
         SSTAMP(tsB);
         if (mine && pA.z > 0) {
-            const long r0 = (long)pA.x - 10;
-            const bool edge = r0 < 0 || r0 + 24 > T;
+            const long r0 = (long)pA.x - H;
+            const bool edge = r0 < 0 || r0 + 2 * NPAIR > T;
             if (staged) {
             } else if (!edge) {
                 const rsrc_t rx = make_rsrc(x + (size_t)r0 * C);
 #pragma unroll
-                for (int m = 0; m < 12; ++m) {
+                for (int m = 0; m < NPAIR; ++m) {
                     xp[m].x = ldb_f32(rx, voff, (2 * m) * rowb);
                     xp[m].y = ldb_f32(rx, voff, (2 * m + 1) * rowb);
                 }
             } else {
 #pragma unroll
-                for (int m = 0; m < 12; ++m) {
+                for (int m = 0; m < NPAIR; ++m) {
                     long ra = r0 + 2 * m, rb = ra + 1;
                     ra = ra < 0 ? 0 : (ra > T - 1 ? T - 1 : ra);
                     rb = rb < 0 ? 0 : (rb > T - 1 ? T - 1 : rb);
@@ -658,25 +663,28 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                     xp[m].y = ldb_f32(make_rsrc(x + (size_t)rb * C), voff, 0);
                 }
             }
-            // smoothing: sequential sums of rows i .. i+20 for the four dayofyears i = 0..3
+            // smoothing: sequential sums of rows i .. i+S-1 for the four dayofyears i = 0..3 (S odd: rows S and S+2 are the
+            // high halves of their pairs)
             v2f accA = (v2f){xp[0].x, -0.0f};
 #pragma unroll
-            for (int s = 1; s <= ((SHIFT_EXP & 16) ? 2 : 20); ++s) accA = (s & 1) ? pk_add_bc_hi(accA, xp[s >> 1]) : pk_add_bc_lo(accA, xp[s >> 1]);
-            accA.y += xp[10].y;
+            for (int s = 1; s <= ((SHIFT_EXP & 16) ? 2 : S - 1); ++s) accA = (s & 1) ? pk_add_bc_hi(accA, xp[s >> 1]) : pk_add_bc_lo(accA, xp[s >> 1]);
+            accA.y += xp[S >> 1].y;
             v2f accB = (v2f){xp[1].x, -0.0f};
 #pragma unroll
-            for (int s = 3; s <= ((SHIFT_EXP & 16) ? 4 : 22); ++s) accB = (s & 1) ? pk_add_bc_hi(accB, xp[s >> 1]) : pk_add_bc_lo(accB, xp[s >> 1]);
-            accB.y += xp[11].y;
+            for (int s = 3; s <= ((SHIFT_EXP & 16) ? 4 : S + 1); ++s) accB = (s & 1) ? pk_add_bc_hi(accB, xp[s >> 1]) : pk_add_bc_lo(accB, xp[s >> 1]);
+            accB.y += xp[(S + 2) >> 1].y;
             smA = div_const2(accA, Sf, yS);
             smB = div_const2(accB, Sf, yS);
             if (edge) {  // windows that leave the series: NaN (a NaN row in the sum, in the general kernel)
                 const long t0 = pA.x;
-                smA.x = (t0 - 10 >= 0 && t0 + 10 < T) ? smA.x : qnan;
-                smA.y = (t0 - 9 >= 0 && t0 + 11 < T) ? smA.y : qnan;
-                smB.x = (t0 - 8 >= 0 && t0 + 12 < T) ? smB.x : qnan;
-                smB.y = (t0 - 7 >= 0 && t0 + 13 < T) ? smB.y : qnan;
+                smA.x = (t0 - H >= 0 && t0 + H < T) ? smA.x : qnan;
+                smA.y = (t0 + 1 - H >= 0 && t0 + 1 + H < T) ? smA.y : qnan;
+                smB.x = (t0 + 2 - H >= 0 && t0 + 2 + H < T) ? smB.x : qnan;
+                smB.y = (t0 + 3 - H >= 0 && t0 + 3 + H < T) ? smB.y : qnan;
             }
-            const v2f xcA = xp[5], xcB = xp[6];
+            // centre rows H .. H+3 of the four dayofyears
+            const v2f xcA = (H & 1) ? (v2f){xp[(H - 1) / 2].y, xp[(H + 1) / 2].x} : xp[H / 2];
+            const v2f xcB = (H & 1) ? (v2f){xp[(H + 1) / 2].y, xp[(H + 3) / 2].x} : xp[H / 2 + 1];
             const bool partial = pA.z < 4;  // only a prefix of the 4 dayofyears exists this year (leap day chunk)
             const bool has1 = pA.z > 1, has2 = pA.z > 2, has3 = pA.z > 3;
             if (!partial) {
@@ -873,15 +881,15 @@ static int launch_shifting(marex_ctx* ctx, const ShiftArgs& a) {
     return 0;
 }
 
-template <int W>
+template <int W, int S = 21>
 static void launch_shift_fast(marex_ctx* ctx, const ShiftArgs& a) {
     const int ncg = (int)((a.C + 63) / 64);
     if (a.tails.lists)
-        hipLaunchKernelGGL((k_shift_fast<W, true>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C,
+        hipLaunchKernelGGL((k_shift_fast<W, true, S>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C,
                            a.fplan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask,
                            a.invalid_count, ncg, 23, a.tails);
     else
-        hipLaunchKernelGGL((k_shift_fast<W, false>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C,
+        hipLaunchKernelGGL((k_shift_fast<W, false, S>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C,
                            a.fplan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask,
                            a.invalid_count, ncg, 23, a.tails);
 }
@@ -912,8 +920,10 @@ static int shifting_impl(marex_ctx* ctx, const char* who, const float* x, int64_
     const int forceD = ctx_opt(ctx, "SHIFT_D", 0);
     const int reg = ctx_opt(ctx, "SHIFT_RING", 1);  // 1 (default): history in registers, 0: LDS ring
     // regular chunks of the calendar go to k_shift_fast (S = 21, instantiated W, arange edge table)
+    // instantiated (W, S): S = 21 with the W list, S = 11 / 15 with W = 5, 10, 15
     const bool fast_w = W == 3 || W == 4 || W == 5 || W == 6 || W == 7 || W == 10 || W == 13 || W == 15;
-    const bool fast_cfg = ctx_opt(ctx, "SHIFT_FAST", 1) != 0 && S == 21 && fast_w && forceD == 0 && T >= 24 &&
+    const bool fast_ws = S == 21 ? fast_w : ((S == 11 || S == 15) && (W == 5 || W == 10 || W == 15));
+    const bool fast_cfg = ctx_opt(ctx, "SHIFT_FAST", 1) != 0 && fast_ws && forceD == 0 && T >= S + 3 &&
                           T_out < (1 << 24) && C < (1 << 24) && MAREX_ABLATE_OPT(ctx, "SHIFT_ABLATE") == 0;
     if (all_fast_possible) *all_fast_possible = fast_cfg;
     if (fast_cfg && !ctx->shift_info) HIP_TRY(ctx, hipMalloc((void**)&ctx->shift_info, SHIFT_INFO_WORDS * sizeof(int)));
@@ -933,6 +943,16 @@ static int shifting_impl(marex_ctx* ctx, const char* who, const float* x, int64_
                            (bins || tails.lists) ? 1 : 0, 1, ctx->shift_info, reinterpret_cast<int4*>(ctx->shift_plan));
         a.skip = ctx->shift_info;
         a.fplan = reinterpret_cast<const int4*>(ctx->shift_plan);
+        if (S == 11 || S == 15) {
+            switch (W * 100 + S) {
+                case 511: launch_shift_fast<5, 11>(ctx, a); break;
+                case 515: launch_shift_fast<5, 15>(ctx, a); break;
+                case 1011: launch_shift_fast<10, 11>(ctx, a); break;
+                case 1015: launch_shift_fast<10, 15>(ctx, a); break;
+                case 1511: launch_shift_fast<15, 11>(ctx, a); break;
+                default: launch_shift_fast<15, 15>(ctx, a); break;
+            }
+        } else
         switch (W) {
             case 3: launch_shift_fast<3>(ctx, a); break;
             case 4: launch_shift_fast<4>(ctx, a); break;

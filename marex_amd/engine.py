@@ -493,11 +493,10 @@ class HotPath:
             binsb, e_ptr, b_ptr, nb = None, None, None, 0
         tail = (T, Cn, dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), use.data_ptr() if use is not None else None, e_ptr, nb,
                 out.data_ptr(), b_ptr, mask.data_ptr(), invalid.data_ptr() if count_invalid else None)
-        if sub is None:
-            rc = self.lib.marex_fixed_baseline_f32(self.ctx.handle, x.data_ptr(), *tail)
-        else:
+        if sub is not None:
             assert sub.dtype == torch.float32 and sub.numel() == Cn
-            rc = self.lib.marex_fixed_baseline_sub_f32(self.ctx.handle, x.data_ptr(), sub.data_ptr(), *tail)
+        nd = int(np.diff(cal.doy_start).max())
+        rc = self.lib.marex_fixed_baseline_sub_f32(self.ctx.handle, x.data_ptr(), sub.data_ptr() if sub is not None else None, nd, *tail)
         self.ctx.check(rc, "marex_fixed_baseline_f32")
         if use is not None:
             self.sync()  # the small table must outlive the kernel
