@@ -209,6 +209,9 @@ extern "C" int marex_digitize_f32(marex_ctx* ctx, const float* anom, int64_t T, 
 // The model tables are tiny ([T, n_coef] float64) and read through the scalar cache (uniform address).
 // ------------------------------------------------------------------------------------------------
 #define DETREND_MAXC 12
+#ifndef DETREND_UNROLL
+#define DETREND_UNROLL 16
+#endif
 #define DETREND_TBLOCK 1024  // timesteps per partial sum (arithmetic contract, oracle.DETREND_TBLOCK)
 
 // Reductions over time are split into blocks of DETREND_TBLOCK timesteps so that the grid is (cell blocks x time
@@ -225,7 +228,7 @@ k_detrend_partial(const float* __restrict__ x, long T, long C, const double* __r
 #pragma unroll
     for (int k = 0; k < DETREND_MAXC; ++k) acc[k] = 0.0;
     int n_invalid = 0;
-#pragma unroll 4
+#pragma unroll DETREND_UNROLL
     for (long t = t0; t < t1; ++t) {
         const float v = x[(size_t)t * C + c];
         n_invalid += finite_f(v) ? 0 : 1;
@@ -263,7 +266,7 @@ k_detrend_resid(const float* __restrict__ x, long T, long C, const double* __res
 #pragma unroll
     for (int k = 0; k < DETREND_MAXC; ++k) cf[k] = k < n_coef ? coef[(size_t)k * C + c] : 0.0;
     double sum = 0.0;
-#pragma unroll 4
+#pragma unroll DETREND_UNROLL
     for (long t = t0; t < t1; ++t) {
         const double* mt = model_t + (size_t)t * n_coef;
         double trend = 0.0;

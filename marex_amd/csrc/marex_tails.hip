@@ -1316,11 +1316,12 @@ extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, co
         hipLaunchKernelGGL(k_row_offsets, dim3((unsigned)((T_out + 255) / 256)), dim3(256), 0, ctx->stream, doy_rows, (long)T_out, (long)C,
                            ctx->row_off, (int)sizeof(float));
 #define MAREX_MT_ARGS tl, aux, NPER, nch, anom, edges, nb, thr_doy_major, doy_start, doy_rows, ctx->row_off_mask, ctx->row_off, (long)C, (long)c0, (long)c1, extreme, n_true, dbg
-        if (NPER <= 1)
+        const int grp = ctx_opt(ctx, "MASK_GROUP", 0);  // lists handled at once (experiments: 1, 2, 3)
+        if (NPER <= 1 || grp == 1)
             hipLaunchKernelGGL(k_mask_tails<1>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, MAREX_MT_ARGS);
-        else if (NPER == 2 || NPER == 4)
+        else if ((NPER != 3 && grp != 3) || grp == 2)  // pairs of lists: 117 VGPRs = four waves per SIMD (three lists: 136)
             hipLaunchKernelGGL(k_mask_tails<2>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, MAREX_MT_ARGS);
-        else  // 3 lists at once; 5, 6, ... lists in groups of 3
+        else  // exactly 3 lists: one group
             hipLaunchKernelGGL(k_mask_tails<3>, dim3(ncb, chunks), dim3(256), 0, ctx->stream, MAREX_MT_ARGS);
 #undef MAREX_MT_ARGS
     }
