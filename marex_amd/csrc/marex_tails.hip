@@ -1079,8 +1079,11 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
 // the anomalies themselves (float4 rows, like the plain mask kernel).
 // Lane = 4 consecutive cells: 16-byte key chunks of 4 cells are one contiguous 64-byte run, mask stores are 4 bytes.
 // ------------------------------------------------------------------------------------------------
+#ifndef MASK_WAVES
+#define MASK_WAVES 5  // waves per SIMD the mask kernel is compiled for (96 VGPRs, a few spilled: 2.24 -> 2.03 ms; 6 is worse)
+#endif
 template <int NPERT>  // lists handled per group (their first chunks are in flight together)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, MASK_WAVES)
 k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ aux, int NPER_all, int nch, const float* __restrict__ anom,
              const float* __restrict__ edges, int nb, const float* __restrict__ thr, const int* __restrict__ doy_start,
              const int* __restrict__ doy_rows, const long long* __restrict__ row_off, const long long* __restrict__ row_off_anom,
