@@ -330,6 +330,10 @@ int marex_label_mesh_i32(marex_ctx* ctx, const uint8_t* data, const uint8_t* mas
  * "shuffle": 1}; examples/batch jobs/run_detect.py:55-83, the fixtures under tests/data).  0 = OK and *out_len = decoded bytes;
  * -5 malformed frame, -6 unsupported codec / filter. */
 int marex_blosc_decompress_h(const void* src, int64_t srclen, void* dst, int64_t dstcap, int64_t* out_len);
+/* Zstandard frames (RFC 8878, no dictionaries; the content checksum is skipped), host pointers: the inner codec of the Blosc
+ * frames of the small coordinate arrays in the reference's stores ({"cname": "zstd"}; xr.open_zarr, run_detect.py:55).
+ * Returns 0 and the decoded length, -5 for a malformed / unsupported stream, never reads or writes out of bounds. */
+int marex_zstd_decompress_h(const uint8_t* src, int64_t srclen, uint8_t* dst, int64_t dstcap, int64_t* out_len);
 
 /* Host-side inverse: compress nbytes bytes into one Blosc-1 frame (LZ4 codec; byte shuffle when shuffle != 0 and
  * typesize > 1; blocksize <= 0 = 256 KiB) -- the chunk format `extremes_ds.to_zarr(...)` produces through numcodecs'

@@ -76,6 +76,7 @@ PROTOTYPES = {
     ),
     "marex_mask_ge_doy_tails_f32": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _i32, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "marex_blosc_decompress_h": (_i32, [_p, _i64, _p, _i64, _p]),
+    "marex_zstd_decompress_h": (_i32, [_p, _i64, _p, _i64, _p]),
     "marex_blosc_compress_h": (_i32, [_p, _i64, _i32, _i32, _i64, _p, _i64, _p]),
     "marex_lz4_decode_streams": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _p, _p]),
     "marex_unshuffle_place": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),

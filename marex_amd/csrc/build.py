@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 UNITS = ["marex_context", "marex_synth", "marex_shifting", "marex_thresholds", "marex_mask", "marex_anomalies",
-         "marex_quantiles", "marex_morphology", "marex_blosc", "marex_tails"]
+         "marex_quantiles", "marex_morphology", "marex_blosc", "marex_tails", "marex_zstd"]
 SRC = [os.path.join(HERE, u + ".hip") for u in UNITS]
 HEADERS = [os.path.join(HERE, "marex_common.hip.h"), os.path.join(HERE, "marex_tails.hip.h"), os.path.join(ROOT, "include", "marex_hip.h")]
 OUT = os.path.join(HERE, "libmarex_hip.so")

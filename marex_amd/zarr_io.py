@@ -3,7 +3,7 @@ store, C order, ``.`` chunk keys, consolidated metadata, Blosc-1 / LZ4 / byte-sh
 ``marex_blosc_compress_h`` / ``marex_blosc_decompress_h`` (host side of the C ABI) or, for reading time-chunked arrays,
 decoded in HBM.  Enough to run the hot path on ``tests/data/*.zarr`` of the reference and to write its result the way
 ``extremes_ds.to_zarr(...)`` does (examples/batch jobs/run_detect.py:55-83); the zstd / bit-shuffle frames of small
-coordinate arrays (lat / lon of ``sst_gridded.zarr``) are decoded on the host with pyarrow's zstd codec when it is present."""
+coordinate arrays (lat / lon of ``sst_gridded.zarr``) are decoded on the host with the library's own zstd decoder."""
 from __future__ import annotations
 
 import ctypes as C
@@ -33,20 +33,32 @@ def _decompress(raw: bytes, nbytes: int) -> bytes:
 def _decompress_foreign(raw: bytes, nbytes: int) -> bytes:
     """Blosc-1 frames the C decoder declines: an inner zstd codec and / or the bit-shuffle filter (the lat / lon arrays of
     the reference's ``sst_gridded.zarr``: ``{"cname": "zstd", "shuffle": 2}``).  Small coordinate arrays only -- the frame
-    is parsed here, zstd streams are handed to pyarrow's codec when that package is present, and the bit transpose is
-    undone with NumPy."""
+    is parsed here, the zstd streams go to the library's own decoder (csrc/marex_zstd.hip), and the bit transpose is undone
+    with NumPy."""
     import struct
 
     _, _, flags, typesize, nb, blocksize, cbytes = struct.unpack("<BBBBIII", raw[:16])
     codec = flags >> 5
     if codec not in (1, 4) or nb != nbytes or cbytes != len(raw):
         raise DependencyError("unsupported Blosc codec (LZ4 and zstd frames are decoded)", details=f"flags {flags:#x}")
-    try:
-        import pyarrow as pa
+    lib = _lib.load()
 
-        dec = pa.Codec("zstd" if codec == 4 else "lz4_raw")
-    except Exception as e:  # pragma: no cover
-        raise DependencyError("this Blosc frame needs pyarrow's zstd codec to be decoded", details=str(e))
+    def inner(stream: bytes, n_out: int) -> bytes:
+        """One compressed split: zstd -> the library's own decoder (csrc/marex_zstd.hip); a raw LZ4 block under the bit-shuffle
+        filter (no store of the reference has one) -> pyarrow's lz4_raw codec when that package is present."""
+        if codec == 4:
+            out = C.create_string_buffer(max(n_out, 1))
+            got = C.c_int64(0)
+            rc = lib.marex_zstd_decompress_h(stream, len(stream), out, n_out, C.byref(got))
+            if rc != 0 or got.value != n_out:
+                raise DataValidationError("malformed Blosc chunk", details=f"zstd stream: code {rc}, decoded {got.value} of {n_out} bytes")
+            return out.raw[:n_out]
+        try:
+            import pyarrow as pa
+        except Exception as e:  # pragma: no cover
+            raise DependencyError("a bit-shuffled LZ4 Blosc frame needs pyarrow's lz4_raw codec to be decoded", details=str(e))
+        return pa.Codec("lz4_raw").decompress(stream, decompressed_size=n_out).to_pybytes()
+
     nblocks = (nbytes + blocksize - 1) // blocksize
     out = bytearray()
     for j in range(nblocks):
@@ -59,7 +71,7 @@ def _decompress_foreign(raw: bytes, nbytes: int) -> bytes:
         for _ in range(nsplits):
             (cb,) = struct.unpack("<i", raw[p: p + 4])
             p += 4
-            blk += raw[p: p + cb] if cb == ne else dec.decompress(raw[p: p + cb], decompressed_size=ne).to_pybytes()
+            blk += raw[p: p + cb] if cb == ne else inner(raw[p: p + cb], ne)
             p += cb
         n_el = bsize // typesize
         if flags & 0x4:  # bit shuffle: row (byte k, bit i) holds that bit of every element, 8 elements per byte, LSB first;
