@@ -758,7 +758,12 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ 
         if (nhigh) atomicAdd(&stats->n_too_high, nhigh);
     }
 #ifdef MAREX_STAMPS
+#ifdef MAREX_STAMPS_WAVE  // phase timers of wave MAREX_STAMPS_WAVE (-1: a different wave per tile) instead of wave 0
+    const int st_wave = MAREX_STAMPS_WAVE >= 0 ? MAREX_STAMPS_WAVE : (int)((blockIdx.x + blockIdx.y) % (NT / 64));
+    if (dbg && t == st_wave * 64) {
+#else
     if (dbg && t == 0) {
+#endif
         atomicAdd(&dbg[5], st_p1);
         atomicAdd(&dbg[6], st_p2);
         atomicAdd(&dbg[7], st_bar);

@@ -12,7 +12,7 @@ bt = binning.hobday_bins()
 tab = synth.make_tables(tm, ny, nx, 20240607, lat_range=(88, 182, 720))
 x = hot.synth_field(tab, cell_base=88*1440)
 wsp = {}
-for tile in (32, 16):
+for tile in (32,):
     with hot.ctx.options(THR_TILE=tile):
         for it in range(2):
             hot.ctx.debug_counters(reset=True)
