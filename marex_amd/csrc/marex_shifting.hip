@@ -452,9 +452,9 @@ __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, 
     if (t < 92) info[t] = s_ok[t] && s_edges_ok;
 }
 
-// TAILS: instead of the bin matrix the kernel emits the sorted key lists of marex_tails.hip.h.  The 16 most recent output
+// TAILS: instead of the bin matrix the kernel emits the sorted key lists of marex_tails.hip.h.  The SHIFT_LIST (15) most recent output
 // years of the wave's 4 dayofyears wait as packed key pairs in LDS (one uniform slot per year, no per-lane counters);
-// every 16th year the wave sorts them (63 packed compare-exchanges per pair of dayofyears) and writes one list per
+// every 15th year the wave sorts them (63 packed compare-exchanges per pair of dayofyears) and writes one list per
 // dayofyear as two 16-byte chunks per lane -- whole 1-KiB lines per wave, nothing is ever read back.
 #ifndef SHIFT_EXP
 #define SHIFT_EXP 0  // timing experiments (wrong results by design), alt builds only: 1 no barriers, 2 no row prefetch, 4 no anomaly stores, 8 no keys, 16 no smoothing sums, 32 no climatology sums
