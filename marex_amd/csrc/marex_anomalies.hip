@@ -217,6 +217,8 @@ extern "C" int marex_digitize_f32(marex_ctx* ctx, const float* anom, int64_t T, 
 // Reductions over time are split into blocks of DETREND_TBLOCK timesteps so that the grid is (cell blocks x time
 // blocks) instead of one thread walking 36 500 rows: float64 partial sums per block in ascending t, combined in
 // ascending block order -- a fixed order, mirrored by the oracle.
+template <int NC>  // NC == n_coef exactly: no per-term branch, and the NC doubles of a model row are ONE wide scalar load (with a
+                   // runtime count every term was its own scalar load + wait: the passes were bound by scalar-load latency)
 __global__ void __launch_bounds__(256)
 k_detrend_partial(const float* __restrict__ x, long T, long C, const double* __restrict__ pmodel /*[T][n]*/, int n_coef,
                   double* __restrict__ partial /*[ntb][n][C]*/, int* __restrict__ invalid_count) {
@@ -224,9 +226,9 @@ k_detrend_partial(const float* __restrict__ x, long T, long C, const double* __r
     if (c >= C) return;
     const long t0 = (long)blockIdx.y * DETREND_TBLOCK;
     const long t1 = t0 + DETREND_TBLOCK < T ? t0 + DETREND_TBLOCK : T;
-    double acc[DETREND_MAXC];
+    double acc[NC];
 #pragma unroll
-    for (int k = 0; k < DETREND_MAXC; ++k) acc[k] = 0.0;
+    for (int k = 0; k < NC; ++k) acc[k] = 0.0;
     int n_invalid = 0;
 #pragma unroll DETREND_UNROLL
     for (long t = t0; t < t1; ++t) {
@@ -235,8 +237,7 @@ k_detrend_partial(const float* __restrict__ x, long T, long C, const double* __r
         const double vd = (double)v;
         const double* pm = pmodel + (size_t)t * n_coef;
 #pragma unroll
-        for (int k = 0; k < DETREND_MAXC; ++k)
-            if (k < n_coef) acc[k] += pm[k] * vd;
+        for (int k = 0; k < NC; ++k) acc[k] += pm[k] * vd;
     }
     for (int k = 0; k < n_coef; ++k) partial[((size_t)blockIdx.y * n_coef + k) * C + c] = acc[k];
     if (invalid_count && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
@@ -255,6 +256,7 @@ k_detrend_combine(const float* __restrict__ x, long C, int ntb, int n_coef, cons
     if (mask) mask[c] = finite_f(x[c]) ? 1 : 0;
 }
 
+template <int NC>
 __global__ void __launch_bounds__(256)
 k_detrend_resid(const float* __restrict__ x, long T, long C, const double* __restrict__ model_t /*[T][n]*/, int n_coef,
                 const double* __restrict__ coef, float* __restrict__ out, double* __restrict__ psum /*[ntb][C]*/) {
@@ -262,17 +264,16 @@ k_detrend_resid(const float* __restrict__ x, long T, long C, const double* __res
     if (c >= C) return;
     const long t0 = (long)blockIdx.y * DETREND_TBLOCK;
     const long t1 = t0 + DETREND_TBLOCK < T ? t0 + DETREND_TBLOCK : T;
-    double cf[DETREND_MAXC];
+    double cf[NC];
 #pragma unroll
-    for (int k = 0; k < DETREND_MAXC; ++k) cf[k] = k < n_coef ? coef[(size_t)k * C + c] : 0.0;
+    for (int k = 0; k < NC; ++k) cf[k] = coef[(size_t)k * C + c];
     double sum = 0.0;
 #pragma unroll DETREND_UNROLL
     for (long t = t0; t < t1; ++t) {
         const double* mt = model_t + (size_t)t * n_coef;
         double trend = 0.0;
 #pragma unroll
-        for (int k = 0; k < DETREND_MAXC; ++k)
-            if (k < n_coef) trend += mt[k] * cf[k];
+        for (int k = 0; k < NC; ++k) trend += mt[k] * cf[k];
         const float r = x[(size_t)t * C + c] - (float)trend;
         out[(size_t)t * C + c] = r;
         sum += (double)r;
@@ -351,12 +352,30 @@ static int detrend_impl(marex_ctx* ctx, const float* x, int64_t T, int64_t C, co
     const unsigned ncb = (unsigned)((C + 255) / 256);
     {
         LaunchTimer lt(ctx, MAREX_K_DETREND);
-        hipLaunchKernelGGL(k_detrend_partial, dim3(ncb, ntb), dim3(256), 0, ctx->stream, x, (long)T, (long)C, pmodel, n_coef,
-                           partial, invalid_count);
+#define MAREX_DETREND_CASE(N)                                                                                                  \
+    case N:                                                                                                                    \
+        hipLaunchKernelGGL(k_detrend_partial<N>, dim3(ncb, ntb), dim3(256), 0, ctx->stream, x, (long)T, (long)C, pmodel, n_coef, \
+                           partial, invalid_count);                                                                            \
+        break;
+        switch (n_coef) {
+            MAREX_DETREND_CASE(1) MAREX_DETREND_CASE(2) MAREX_DETREND_CASE(3) MAREX_DETREND_CASE(4) MAREX_DETREND_CASE(5)
+            MAREX_DETREND_CASE(6) MAREX_DETREND_CASE(7) MAREX_DETREND_CASE(8) MAREX_DETREND_CASE(9) MAREX_DETREND_CASE(10)
+            MAREX_DETREND_CASE(11) MAREX_DETREND_CASE(12)
+        }
+#undef MAREX_DETREND_CASE
         hipLaunchKernelGGL(k_detrend_combine, dim3(ncb), dim3(256), 0, ctx->stream, x, (long)C, ntb, n_coef, partial, coef,
                            mask);
-        hipLaunchKernelGGL(k_detrend_resid, dim3(ncb, ntb), dim3(256), 0, ctx->stream, x, (long)T, (long)C, model_t, n_coef,
-                           coef, out, partial);
+#define MAREX_DETREND_CASE(N)                                                                                                  \
+    case N:                                                                                                                    \
+        hipLaunchKernelGGL(k_detrend_resid<N>, dim3(ncb, ntb), dim3(256), 0, ctx->stream, x, (long)T, (long)C, model_t, n_coef, \
+                           coef, out, partial);                                                                                \
+        break;
+        switch (n_coef) {
+            MAREX_DETREND_CASE(1) MAREX_DETREND_CASE(2) MAREX_DETREND_CASE(3) MAREX_DETREND_CASE(4) MAREX_DETREND_CASE(5)
+            MAREX_DETREND_CASE(6) MAREX_DETREND_CASE(7) MAREX_DETREND_CASE(8) MAREX_DETREND_CASE(9) MAREX_DETREND_CASE(10)
+            MAREX_DETREND_CASE(11) MAREX_DETREND_CASE(12)
+        }
+#undef MAREX_DETREND_CASE
         if (force_zero_mean && mean_out) {  // the caller subtracts (marex_fixed_baseline_sub_f32 does it on load)
             hipLaunchKernelGGL(k_detrend_mean, dim3(ncb), dim3(256), 0, ctx->stream, (long)T, (long)C, ntb, partial, mean_out);
         } else if (force_zero_mean) {
