@@ -244,6 +244,16 @@ int marex_detrend_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, cons
 int marex_detrend_deferred_mean_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
                                     const double* model_t, int n_coef, float* out, float* mean, uint8_t* mask,
                                     int32_t* invalid_count);
+/* detect.py:2400-2462 (detrend_fixed_baseline) as one chain: fit, residual mean, and the daily climatology stage recomputing
+ * the residuals from x while it reads (3 reads and 1 write of the field; the residual field is never materialised).
+ * n_coef <= 5 and max_bucket <= 128, else -4 (run marex_detrend_deferred_mean_f32 + marex_fixed_baseline_sub_f32 instead).
+ * model_sorted[r][k] = model_t[doy_rows[r]][k]: the model rows in dayofyear-sorted row order (contiguous per bucket).
+ * mask / invalid_count: of the RAW field, as marex_detrend_f32 reports them. */
+int marex_detrend_fixed_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
+                                     const double* model_t, const double* model_sorted, int n_coef, int force_zero_mean,
+                                     const int32_t* doy_start,
+                                     const int32_t* doy_rows, const uint8_t* use_row, int max_bucket, float* out,
+                                     uint8_t* mask, int32_t* invalid_count);
 
 /*
  * Exact Hobday percentile (detect.py:1921-1956): thr[d, c] = np.nanpercentile(anom[doy in window(d), c], p),

@@ -48,6 +48,7 @@ PROTOTYPES = {
     "marex_digitize_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _i64, _p]),
     "marex_detrend_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
     "marex_detrend_deferred_mean_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p]),
+    "marex_detrend_fixed_baseline_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p]),
     "marex_fixed_baseline_sub_f32": (_i32, [_p, _p, _p, _i32, _i64, _i64, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     "marex_hobday_exact_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _f32, _f64, _i32, _p, _p]),
     "marex_global_threshold_f32": (_i32, [_p, _p, _i64, _i64, _f64, _i32, _p, _p, _i32, _f64, _f64, _p, _p, _p]),

@@ -57,11 +57,15 @@ k_fixed_baseline(const float* __restrict__ x, long T, long C, const int* __restr
 // sum and the subtraction, so the field is read once (k_fixed_baseline's second read of a 100-year bucket does not come from
 // the L2: 205 MB of buckets are in flight at full occupancy -- measured 39 GB of reads for a 19.7 GB band) and up to NMAX
 // loads per lane are in flight (two waves per SIMD are plenty for a stream like that).
-template <int NMAX>
+// NC > 0: x is the RAW field and the sample is its detrend residual, x - fl32(sum_k model_t[t][k] * coef[k][c]) (the arithmetic of
+// k_detrend_resid, recomputed here so that the residual field is never written or read: detrend_fixed_baseline in 3 reads and
+// 1 write of the field).
+template <int NMAX, int NC = 0>
 __global__ void __launch_bounds__(256)
 k_fixed_baseline_reg(const float* __restrict__ x, long C, const int* __restrict__ doy_start, const int* __restrict__ doy_rows,
                      const unsigned char* __restrict__ use_row, float* __restrict__ out, unsigned char* __restrict__ mask,
-                     int* __restrict__ invalid_count, const float* __restrict__ sub) {
+                     int* __restrict__ invalid_count, const float* __restrict__ sub, const double* __restrict__ model_t = nullptr,
+                     const double* __restrict__ coef = nullptr) {
     const int d = blockIdx.y;
     const long c_raw = (long)blockIdx.x * 256 + threadIdx.x;
     const bool active = c_raw < C;
@@ -70,6 +74,9 @@ k_fixed_baseline_reg(const float* __restrict__ x, long C, const int* __restrict_
     const int r0 = doy_start[d], nrow = doy_start[d + 1] - r0;  // uniform, <= NMAX
     const bool has_sub = sub != nullptr;
     const float sc = has_sub ? sub[c] : 0.f;
+    double cf[NC > 0 ? NC : 1];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) cf[k] = coef[(size_t)k * C + c];
     float v[NMAX];
 #pragma unroll
     for (int b = 0; b < NMAX; b += 16) {
@@ -77,6 +84,24 @@ k_fixed_baseline_reg(const float* __restrict__ x, long C, const int* __restrict_
 #pragma unroll
             for (int u = 0; u < 16; ++u)
                 if (b + u < nrow) v[b + u] = x[(size_t)doy_rows[r0 + b + u] * C + c];
+        }
+    }
+    if (NC > 0) {  // a second walk, so that the loads above are all in flight before the first residual is formed
+#pragma unroll
+        for (int b = 0; b < NMAX; b += 16) {
+            if (b < nrow) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (b + u < nrow) {
+                        // model rows in BUCKET order (model_t here = the caller's table permuted by doy_rows): the rows of a
+                        // batch are contiguous, one wide scalar load instead of a dependent load per row
+                        const double* mt = model_t + (size_t)(r0 + b + u) * NC;
+                        double trend = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NC; ++k) trend += mt[k] * cf[k];
+                        v[b + u] = v[b + u] - (float)trend;
+                    }
+            }
         }
     }
     float acc = 0.f;
@@ -275,7 +300,7 @@ k_detrend_resid(const float* __restrict__ x, long T, long C, const double* __res
 #pragma unroll
         for (int k = 0; k < NC; ++k) trend += mt[k] * cf[k];
         const float r = x[(size_t)t * C + c] - (float)trend;
-        out[(size_t)t * C + c] = r;
+        if (out) out[(size_t)t * C + c] = r;  // null: only the sum is wanted (marex_detrend_fixed_baseline_f32)
         sum += (double)r;
     }
     psum[(size_t)blockIdx.y * C + c] = sum;
@@ -313,8 +338,11 @@ k_detrend_sub(long T, long C, const float* __restrict__ mean, float* __restrict_
     }
 }
 
+// coefs_only: no residual field is produced (out may be null) -- the fit, and with force_zero_mean the residual's mean into the
+// context's scratch; *coef_dev / *mean_dev return where they are
 static int detrend_impl(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel, const double* model_t,
-                        int n_coef, int force_zero_mean, float* out, uint8_t* mask, int32_t* invalid_count, float* mean_out);
+                        int n_coef, int force_zero_mean, float* out, uint8_t* mask, int32_t* invalid_count, float* mean_out,
+                        bool coefs_only = false, const double** coef_dev = nullptr, const float** mean_dev = nullptr);
 
 extern "C" int marex_detrend_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
                                  const double* model_t, int n_coef, int force_zero_mean, float* out, uint8_t* mask,
@@ -329,10 +357,50 @@ extern "C" int marex_detrend_deferred_mean_f32(marex_ctx* ctx, const float* x, i
     return detrend_impl(ctx, x, T, C, pmodel, model_t, n_coef, 1, out, mask, invalid_count, mean);
 }
 
-static int detrend_impl(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel, const double* model_t,
-                        int n_coef, int force_zero_mean, float* out, uint8_t* mask, int32_t* invalid_count, float* mean_out) {
+// detrend_fixed_baseline (detect.py:2400-2462) as one chain: fit (one read of x), residual mean (one read, nothing written),
+// then the climatology kernel recomputes every residual from x while it reads its dayofyear bucket (one read, one write).
+// Covers n_coef <= 5 and buckets <= 128 rows; -4 otherwise (callers then run the two stages separately).
+extern "C" int marex_detrend_fixed_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
+                                                const double* model_t, const double* model_sorted, int n_coef, int force_zero_mean,
+                                                const int32_t* doy_start,
+                                                const int32_t* doy_rows, const uint8_t* use_row, int max_bucket, float* out,
+                                                uint8_t* mask, int32_t* invalid_count) {
     if (!ctx) return -1;
-    if (!x || !pmodel || !model_t || !out || T <= 0 || C <= 0) return fail(ctx, -1, "marex_detrend_f32: null pointer or empty shape");
+    if (!x || !pmodel || !model_t || !model_sorted || !doy_start || !doy_rows || !out || T <= 0 || C <= 0)
+        return fail(ctx, -1, "marex_detrend_fixed_baseline_f32: null pointer or empty shape");
+    if (n_coef < 1 || n_coef > 5 || max_bucket < 1 || max_bucket > 128)
+        return fail(ctx, -4, "marex_detrend_fixed_baseline_f32: covers 1..5 coefficients and buckets of at most 128 rows");
+    const double* coef = nullptr;
+    const float* mean = nullptr;
+    const int rc = detrend_impl(ctx, x, T, C, pmodel, model_t, n_coef, force_zero_mean, nullptr, mask, invalid_count, nullptr, true,
+                                &coef, &mean);
+    if (rc != 0) return rc;
+    const float* sub = force_zero_mean ? mean : nullptr;
+    dim3 grid((unsigned)((C + 255) / 256), NDOY);
+    {
+        LaunchTimer lt(ctx, MAREX_K_FIXED);
+#define MAREX_DF_CASE(N)                                                                                                          \
+    case N:                                                                                                                       \
+        if (max_bucket <= 48)                                                                                                     \
+            hipLaunchKernelGGL((k_fixed_baseline_reg<48, N>), grid, dim3(256), 0, ctx->stream, x, (long)C, doy_start, doy_rows, use_row, \
+                               out, nullptr, nullptr, sub, model_sorted, coef);                                                  \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((k_fixed_baseline_reg<128, N>), grid, dim3(256), 0, ctx->stream, x, (long)C, doy_start, doy_rows, use_row, \
+                               out, nullptr, nullptr, sub, model_sorted, coef);                                                  \
+        break;
+        switch (n_coef) { MAREX_DF_CASE(1) MAREX_DF_CASE(2) MAREX_DF_CASE(3) MAREX_DF_CASE(4) MAREX_DF_CASE(5) }
+#undef MAREX_DF_CASE
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+static int detrend_impl(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel, const double* model_t,
+                        int n_coef, int force_zero_mean, float* out, uint8_t* mask, int32_t* invalid_count, float* mean_out,
+                        bool coefs_only, const double** coef_dev, const float** mean_dev) {
+    if (!ctx) return -1;
+    if (!x || !pmodel || !model_t || (!out && !coefs_only) || T <= 0 || C <= 0)
+        return fail(ctx, -1, "marex_detrend_f32: null pointer or empty shape");
     if (n_coef < 1 || n_coef > DETREND_MAXC) return fail(ctx, -4, "marex_detrend_f32: n_coef must be in 1..%d", DETREND_MAXC);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int ntb = (int)((T + DETREND_TBLOCK - 1) / DETREND_TBLOCK);
@@ -349,6 +417,12 @@ static int detrend_impl(marex_ctx* ctx, const float* x, int64_t T, int64_t C, co
     double* coef = partial + (size_t)ntb * n_coef * C;
     float* mean = reinterpret_cast<float*>(coef + (size_t)n_coef * C);
     if (invalid_count) HIP_TRY(ctx, hipMemsetAsync(invalid_count, 0, (size_t)C * sizeof(int), ctx->stream));
+    if (coef_dev) *coef_dev = coef;
+    if (mean_dev) *mean_dev = mean;
+    if (coefs_only) {
+        out = nullptr;
+        mean_out = mean;
+    }
     const unsigned ncb = (unsigned)((C + 255) / 256);
     {
         LaunchTimer lt(ctx, MAREX_K_DETREND);
@@ -370,6 +444,7 @@ static int detrend_impl(marex_ctx* ctx, const float* x, int64_t T, int64_t C, co
         hipLaunchKernelGGL(k_detrend_resid<N>, dim3(ncb, ntb), dim3(256), 0, ctx->stream, x, (long)T, (long)C, model_t, n_coef, \
                            coef, out, partial);                                                                                \
         break;
+        if (!coefs_only || force_zero_mean)  // coefficients only and no mean wanted: the residual pass has nothing to do
         switch (n_coef) {
             MAREX_DETREND_CASE(1) MAREX_DETREND_CASE(2) MAREX_DETREND_CASE(3) MAREX_DETREND_CASE(4) MAREX_DETREND_CASE(5)
             MAREX_DETREND_CASE(6) MAREX_DETREND_CASE(7) MAREX_DETREND_CASE(8) MAREX_DETREND_CASE(9) MAREX_DETREND_CASE(10)

@@ -481,10 +481,12 @@ def _anomaly_core(eng, field: _Field, method_anomaly, window_year_baseline, smoo
         model, pmodel = calendar.detrend_model(calendar.decimal_year(field.time), detrend_orders, harm)
         if method_anomaly == "detrend_fixed_baseline":
             _check_reference_period_values(reference_period, cal.year)
-            # the residual mean is subtracted by the climatology kernel while it reads (one pass over the field less)
-            d = eng.detrend(x, model, pmodel, bool(force_zero_mean), None, count_invalid=True, defer_mean=True)
-            r = eng.fixed_baseline(d["out"], dcal, reference_period, want_bins, count_invalid=False, sub=d.get("mean"))
-            r["mask"], r["invalid_count"] = d["mask"], d["invalid_count"]
+            if want_bins is None:  # one chain on the device; the residual field is never materialised
+                r = eng.detrend_fixed_baseline(x, model, pmodel, bool(force_zero_mean), dcal, reference_period)
+            else:  # a bin matrix is wanted: the two stages, the residual mean subtracted by the climatology kernel while it reads
+                d = eng.detrend(x, model, pmodel, bool(force_zero_mean), None, count_invalid=True, defer_mean=True)
+                r = eng.fixed_baseline(d["out"], dcal, reference_period, want_bins, count_invalid=False, sub=d.get("mean"))
+                r["mask"], r["invalid_count"] = d["mask"], d["invalid_count"]
         else:
             r = eng.detrend(x, model, pmodel, bool(force_zero_mean), (want_bins, dcal), count_invalid=True)
     else:

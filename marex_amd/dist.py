@@ -136,10 +136,9 @@ def shard_step(hot, shards, xs, dcal, *, W: int = 15, S: int = 21, bins, q: floa
             r = hot.shifting_hobday(x, dcal, W=W, S=S, bins=bins, q=q, wd=wd, ws=ws, ny=ny_s, nx=nx_s, own_rows=rows,
                                     workspace=workspace)
         else:
-            d = hot.detrend(x, detrend[0], detrend[1], True, None, count_invalid=True, wsp=workspace, defer_mean=True)
-            f = hot.fixed_baseline(d["out"], dcal, None, None, count_invalid=False, wsp=workspace, sub=d.get("mean"))
+            f = hot.detrend_fixed_baseline(x, detrend[0], detrend[1], True, dcal, None, wsp=workspace)
             h = hot.hobday_approx(f["out"], dcal, bins, q, wd, ws, ny_s, nx_s, rows=rows, cells=(own.start, own.stop), wsp=workspace)
-            r = {"dat_anomaly": f["out"], "mask": d["mask"], "invalid_count": d["invalid_count"], "thr_doy_major": h["thr_doy_major"],
+            r = {"dat_anomaly": f["out"], "mask": f["mask"], "invalid_count": f["invalid_count"], "thr_doy_major": h["thr_doy_major"],
                  "stats_dev": h["stats_dev"], "extreme_events": h["extreme"], "n_true": h["n_true"], "path": h["path"]}
         vs = hot.validation_summary(r["mask"], r["invalid_count"], (own.start, own.stop), workspace)  # a3 verdict
         st = r["stats_dev"]

@@ -563,6 +563,40 @@ class HotPath:
             res["bins"] = self.digitize(out, bins_and_cal[1], bins_and_cal[0], wsp=wsp)
         return res
 
+    def detrend_fixed_baseline(self, x: torch.Tensor, model: np.ndarray, pmodel: np.ndarray, force_zero_mean: bool,
+                               dcal: DeviceCalendar, reference_period=None, wsp: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+        """``detrend_fixed_baseline`` (detect.py:2400-2462): residual of the fit minus its daily climatology.  One chain on the
+        device when the model has at most 5 terms and dayofyear buckets at most 128 rows (the residual field is never
+        materialised: 3 reads and 1 write of the field), otherwise the two stages one after the other.  Same bits either way."""
+        T, Cn = x.shape
+        cal = dcal.plan
+        n_coef = int(model.shape[0])
+        nd = int(np.diff(cal.doy_start).max())
+        if n_coef > 5 or nd > 128 or not self.ctx_opt("DETREND_FUSED", 1):
+            d = self.detrend(x, model, pmodel, bool(force_zero_mean), None, count_invalid=True, wsp=wsp, defer_mean=True)
+            r = self.fixed_baseline(d["out"], dcal, reference_period, None, count_invalid=False, wsp=wsp, sub=d.get("mean"))
+            return {"out": r["out"], "mask": d["mask"], "invalid_count": d["invalid_count"]}
+        self._bind_stream()
+        assert x.dtype == torch.float32 and x.is_contiguous() and cal.T == T and cal.T_out == T
+        pm = self._dev(np.ascontiguousarray(pmodel, dtype=np.float64))
+        mt_host = np.ascontiguousarray(model.T, dtype=np.float64)
+        mt = self._dev(mt_host)
+        mts = self._dev(np.ascontiguousarray(mt_host[cal.doy_rows]))  # model rows in dayofyear-sorted row order
+        use = None
+        if reference_period is not None:
+            use = self._dev(((cal.year >= reference_period[0]) & (cal.year <= reference_period[1])).astype(np.uint8))
+        out = self._buf(wsp, "anom", (T, Cn), torch.float32, self.device)
+        mask = self._buf(wsp, "mask", (Cn,), torch.uint8, self.device)
+        invalid = self._buf(wsp, "invalid", (Cn,), torch.int32, self.device)
+        rc = self.lib.marex_detrend_fixed_baseline_f32(
+            self.ctx.handle, x.data_ptr(), T, Cn, pm.data_ptr(), mt.data_ptr(), mts.data_ptr(), n_coef, int(bool(force_zero_mean)),
+            dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), use.data_ptr() if use is not None else None, nd,
+            out.data_ptr(), mask.data_ptr(), invalid.data_ptr(),
+        )
+        self.ctx.check(rc, "marex_detrend_fixed_baseline_f32")
+        self.sync()  # pm / mt / use must outlive the kernels
+        return {"out": out, "mask": mask, "invalid_count": invalid}
+
     # ------------------------------------------------------------------ stage a9 exact Hobday
     def std_normalise(self, anom: torch.Tensor, dcal: DeviceCalendar, window: int = 30,
                       wsp: Optional[dict] = None) -> Dict[str, torch.Tensor]:

@@ -69,3 +69,43 @@ def test_detrend_then_fixed_baseline_and_digitize(hot):
     hot.sync()
     assert _same(f["out"].cpu().numpy(), exp)
     assert np.array_equal(hot.bins_to_rows(b, x.shape[1]).cpu().numpy().view(np.uint16), orc.digitize_bins(exp, bt.edges)[cal.doy_rows])
+
+
+@pytest.mark.parametrize("orders,fzm,ref,years", [([1], True, None, 8), ([1, 2], True, (2001, 2005), 11), ([1, 2, 3], False, None, 9),
+                                                  ([1, 2, 3, 4], True, None, 60), ([2], False, (1999, 2003), 6)])
+def test_detrend_fixed_baseline_as_one_chain(hot, orders, fzm, ref, years):
+    """marex_detrend_fixed_baseline_f32 (fit, residual mean, climatology kernel recomputing the residuals from x) against the
+    oracle and against the two stages run one after the other: same bits; the deferred-mean pair likewise; 60 years exercise
+    the 128-row bucket instance, gaps and a late-starting cell the NaN handling, six terms the fall-back to the two stages."""
+    tm, x = _field("1998-02-01", years * 365 + years // 4, 5, 17)
+    x[300:340, 3] = np.nan
+    x[:500, 4] = np.nan
+    cal = calendar.build_calendar(tm)
+    model, pmodel = calendar.detrend_model(calendar.decimal_year(tm), orders, False)
+    exp_d = orc.detrend_anomaly(x, model, pmodel, fzm)
+    exp, _ = orc.fixed_baseline_anomaly(exp_d, cal, ref)
+    dcal = hot.upload_calendar(cal)
+    xd = torch.from_numpy(x).to(hot.device)
+    got = hot.detrend_fixed_baseline(xd, model, pmodel, fzm, dcal, ref)
+    hot.sync()
+    assert _same(got["out"].cpu().numpy(), exp)
+    assert np.array_equal(got["mask"].cpu().numpy().astype(bool), np.isfinite(x[0]))
+    assert np.array_equal(got["invalid_count"].cpu().numpy(), (~np.isfinite(x)).sum(axis=0))
+    with hot.ctx.options(DETREND_FUSED=0):
+        two = hot.detrend_fixed_baseline(xd, model, pmodel, fzm, dcal, ref)
+        hot.sync()
+    assert np.array_equal(got["out"].cpu().numpy(), two["out"].cpu().numpy(), equal_nan=True)
+    with hot.ctx.options(DETREND_FUSED=0, FIXED_REG=0):  # and the two-read climatology kernel
+        old = hot.detrend_fixed_baseline(xd, model, pmodel, fzm, dcal, ref)
+        hot.sync()
+    assert np.array_equal(got["out"].cpu().numpy(), old["out"].cpu().numpy(), equal_nan=True)
+
+
+def test_detrend_fixed_baseline_falls_back_beyond_five_terms(hot):
+    tm, x = _field("2000-01-01", 7 * 365 + 2, 4, 9)
+    cal = calendar.build_calendar(tm)
+    model, pmodel = calendar.detrend_model(calendar.decimal_year(tm), [1, 2, 3, 4, 5], False)  # six terms
+    exp, _ = orc.fixed_baseline_anomaly(orc.detrend_anomaly(x, model, pmodel, True), cal, None)
+    got = hot.detrend_fixed_baseline(torch.from_numpy(x).to(hot.device), model, pmodel, True, hot.upload_calendar(cal), None)
+    hot.sync()
+    assert _same(got["out"].cpu().numpy(), exp)
