@@ -1,7 +1,8 @@
 """CPU: the Zstandard decoder written from the format description (csrc/marex_zstd.hip, host side) against an independent
 implementation (pyarrow's bundled libzstd as ENCODER and reference decoder): literal and sequence modes of every compression
 level family, raw / RLE blocks, multi-block and multi-frame streams, skippable frames -- and malformed input (truncations, bit
-flips), which must come back as an error code or as different bytes, never as a crash."""
+flips), which must come back as an error code or as different bytes, never as a crash.  (The sanitizer run of the host build
+lives in tests/test_zstd_sanitizers.py, a CPU-only file that does not travel to the GPU box.)"""
 import ctypes as C
 
 import numpy as np
@@ -87,40 +88,3 @@ def test_malformed_streams_never_crash():
             n_err += rc != 0
     assert n_err > 0
 
-
-def test_decoder_under_address_and_ub_sanitizers(tmp_path):
-    """The host build of the decoder with -fsanitize=address,undefined over a corpus of valid, truncated, bit-flipped and
-    byte-stuffed streams, each in exact-size heap buffers (tests/host/zstd_sanitizer_harness.cpp): no report, no crash."""
-    import os
-    import shutil
-    import subprocess
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("no hipcc")
-    exe = str(tmp_path / "zasan")
-    subprocess.check_call([hipcc, "--cuda-host-only", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-O1", "-std=c++17",
-                           "-I" + os.path.join(root, "include"), os.path.join(root, "marex_amd", "csrc", "marex_zstd.hip"),
-                           os.path.join(root, "tests", "host", "zstd_sanitizer_harness.cpp"), "-o", exe],
-                          cwd=os.path.join(root, "marex_amd", "csrc"), stderr=subprocess.DEVNULL)
-    rng = np.random.default_rng(5)
-    k = 0
-    for lvl in (1, 19):
-        codec = pa.Codec("zstd", compression_level=lvl)
-        for raw in _cases().values():
-            comp = bytearray(codec.compress(raw, asbytes=True))
-            for j in range(24):
-                bad = bytearray(comp)
-                if j % 4 == 1:
-                    bad = bad[: int(rng.integers(0, len(bad) + 1))]
-                elif j % 4 == 2:
-                    for _ in range(int(rng.integers(1, 5))):
-                        bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
-                elif j % 4 == 3:
-                    i = int(rng.integers(0, len(bad) + 1))
-                    bad[i:i] = bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8))
-                (tmp_path / f"c{k:05d}_{len(raw)}.bin").write_bytes(bytes(bad))
-                k += 1
-    out = subprocess.run([exe], cwd=str(tmp_path), capture_output=True, text=True, env={**os.environ, "ASAN_OPTIONS": "detect_leaks=0"})
-    assert out.returncode == 0 and "streams" in out.stdout and "ERROR" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-2000:]
