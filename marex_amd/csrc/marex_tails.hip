@@ -788,6 +788,8 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ 
 // samples of many lists), and the rare probe it does not decide -- some list with its whole first chunk at or above the probe while
 // the total is still short -- is recounted from the full lists.
 // ------------------------------------------------------------------------------------------------
+template <int NSC>  // NSC > 0: the ring has exactly NSC slots and a day's probes count from a REGISTER copy of it (one LDS read of
+                    // the ring per day instead of one per probe: the probes of a day form a dependent chain, LDS latency included)
 __global__ void __launch_bounds__(64)
 k_thr_cells(const uint4* __restrict__ lists, const unsigned short* __restrict__ aux, int NPER, int nch, const float* __restrict__ anom,
             long C, long c0, long c1, int nblk, const float* __restrict__ centres, int nb, double q, int wd, float lower_bound,
@@ -822,9 +824,17 @@ k_thr_cells(const uint4* __restrict__ lists, const unsigned short* __restrict__ 
         tot += cnt_of(day);
     }
     // lower bound of #(keys >= first key of bin b) from the ring
+    uint4 cache[NSC > 0 ? NSC : 1];
     auto count_ring = [&](int b) {
         const unsigned lim = ((unsigned)(b + 1) << TAIL_POS_BITS) - 1u, lim_rep = lim | (lim << 16);
         unsigned acc0 = 0, acc1 = 0;
+        if (NSC > 0) {
+#pragma unroll
+            for (int k = 0; k < NSC; ++k) {
+                acc0 += pk_min1_u16(pk_sub_sat_u16(cache[k].x, lim_rep)) + pk_min1_u16(pk_sub_sat_u16(cache[k].z, lim_rep));
+                acc1 += pk_min1_u16(pk_sub_sat_u16(cache[k].y, lim_rep)) + pk_min1_u16(pk_sub_sat_u16(cache[k].w, lim_rep));
+            }
+        } else
         for (int k = 0; k < nslot; k += 4) {  // four lists in flight per trip
             const uint4 c[4] = {mine[k * 64], mine[(k + 1) * 64], mine[(k + 2) * 64], mine[(k + 3) * 64]};
 #pragma unroll
@@ -854,6 +864,10 @@ k_thr_cells(const uint4* __restrict__ lists, const unsigned short* __restrict__ 
             const int din = wrap(d + pd), dout = wrap(d - pd - 1);
             load_day(din, d - d_begin - 1);
             tot += cnt_of(din) - cnt_of(dout);
+        }
+        if (NSC > 0) {
+#pragma unroll
+            for (int k = 0; k < NSC; ++k) cache[k] = mine[k * 64];
         }
         // kfull = largest last key of a first chunk: a probe at or below it may be missing keys the ring does not hold;
         // khead = largest key of the window: no sample lies in a bin above its bin
@@ -1003,8 +1017,10 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
         nblk = ctx_opt(ctx, "THR_CELLS_BLOCKS", nblk);
         LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
         const size_t lds = (size_t)((wd * NPER + 3) & ~3) * 64 * sizeof(uint4);
-        if (lds > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_thr_cells, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_thr_cells, dim3((unsigned)ncg, (unsigned)nblk), dim3(64), lds, ctx->stream,
+        const int nslot = (wd * NPER + 3) & ~3;
+        const bool cached = nslot == 12 && ctx_opt(ctx, "THR_CELLS_CACHE", 1);  // the default 11-day window of single-list buckets
+        if (lds > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_thr_cells<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(cached ? k_thr_cells<12> : k_thr_cells<0>, dim3((unsigned)ncg, (unsigned)nblk), dim3(64), lds, ctx->stream,
                            reinterpret_cast<const uint4*>(lists), aux, NPER, nch, anom, (long)C, c0, c1, nblk, centres, nb, q, wd,
                            lower_bound, upper_bound, thr_doy_major, stats, ctx_debug_counters(ctx));
         HIP_TRY(ctx, hipGetLastError());
