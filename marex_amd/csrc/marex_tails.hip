@@ -1009,7 +1009,11 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
     int NPER, nch;
     if (!tails_geometry(max_bucket, list_rows, NPER, nch))
         return fail(ctx, -4, "marex_hobday_thresholds_tails_f32: %d rows per bucket in lists of %d", max_bucket, list_rows);
-    if (p == 0 && wd * NPER <= 128 && ctx_opt(ctx, "THR_CELLS", 1)) {  // no spatial pooling: one lane per cell, no tiles
+    // no spatial pooling: one lane per cell, no tiles -- while the window is a dozen lists (measured on 0.5 M cells: 12 slots 7.9 ms
+    // against 24.9 ms for the tile kernel; 24 slots 17.7 against 13.3: a probe's cost grows with the lists, the tile kernel's
+    // column update does not).  THR_CELLS=2 forces it for any window that fits the LDS.
+    const int cells_opt = ctx_opt(ctx, "THR_CELLS", 1);
+    if (p == 0 && cells_opt && (cells_opt == 2 ? wd * NPER <= 128 : wd * NPER <= 16)) {
         const long c0 = ny > 0 ? (long)row0 * nx : 0, c1 = ny > 0 ? (long)row1 * nx : (long)C;
         const long ncg = (c1 - c0 + 63) / 64;
         int nblk = (int)((32L * 4 * device_cus(ctx) + ncg - 1) / ncg);  // several rounds of waves (an even finish); every block re-reads wd - 1 buckets

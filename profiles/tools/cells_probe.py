@@ -5,7 +5,8 @@ import torch
 from marex_amd import binning, calendar, synth
 from marex_amd.engine import HotPath
 hot = HotPath(0)
-C, T = int(sys.argv[1]) if len(sys.argv) > 1 else 500000, 10957
+C = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 10957
 tm = calendar.daily_time_axis("1990-01-01", T)
 cal = calendar.build_calendar(tm, window_year_baseline=15)
 dcal = hot.upload_calendar(cal)
@@ -15,7 +16,7 @@ wsp = {}
 a = hot.shifting_baseline_tails(x, dcal, 15, 21, bt, wsp=wsp)
 tl = a["tails"]
 print("max_bucket", tl["max_bucket"], "list_rows", tl["list_rows"], "lists", tuple(tl["tails"].shape))
-for opts in [{}] + [{"THR_CELLS_BLOCKS": b} for b in (2, 3, 4, 6, 8, 12)] + [{"THR_CELLS": 0}]:
+for opts in [{}, {"THR_CELLS_CACHE": 0}, {"THR_CELLS": 0}]:
     with hot.ctx.options(**opts):
         for it in range(3):
             if it == 1:

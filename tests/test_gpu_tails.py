@@ -204,10 +204,12 @@ def test_per_cell_threshold_kernel_without_spatial_pooling(hot, years, pct, wd, 
     anom[:, 7] = np.float32(0.25)                     # ties: every sample in one bin
     anom[:, 8] = np.float32(7.0)                      # nothing countable
     bt = binning.hobday_bins()
-    c = _thr_case(hot, anom, cal, bt, pct, wd, None, 0, 333, list_rows=list_rows)
-    if pct == 60.0:
+    c = _thr_case(hot, anom, cal, bt, pct, wd, None, 0, 333, list_rows=list_rows, opts={"THR_CELLS": 2})  # forced: by default only
+    if pct == 60.0:                                                                                    # windows of <= 16 lists
         assert c[1] > 0, c                            # probes the first chunks could not decide
     c0 = _thr_case(hot, anom, cal, bt, pct, wd, None, 0, 333, list_rows=list_rows, opts={"THR_CELLS": 0})  # the tile kernel, same bits
     assert c0[1] == 0
     if years <= 30:  # gridded field asked for ws = 1, owned rows only, several day blocks
-        _thr_case(hot, anom[:, :330].copy(), cal, bt, pct, wd, 1, 11, 30, rows=(2, 9), list_rows=list_rows, opts={"THR_CELLS_BLOCKS": 5})
+        _thr_case(hot, anom[:, :330].copy(), cal, bt, pct, wd, 1, 11, 30, rows=(2, 9), list_rows=list_rows,
+                  opts={"THR_CELLS": 2, "THR_CELLS_BLOCKS": 5})
+        _thr_case(hot, anom[:, :330].copy(), cal, bt, pct, wd, 1, 11, 30, rows=(2, 9), list_rows=list_rows)  # the default choice
