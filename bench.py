@@ -377,12 +377,23 @@ def main():
             "kernel_ms": avg_ms,
         }
         if world == 1 and not args.no_extra and detrend is None:
+            # untimed additions: a failure here (say, no room left for the second engine's workspace) must not cost the line
             out["extra"] = {}
             if len(shards) > 1:  # before the seasonal line: that one overwrites band 0
-                out["extra"]["two_streams"] = streams_extra(local_rank, shards, xs, cal, step_kw, units)
-            out["extra"]["seasonal_field"] = seasonal_extra(hot, shards[0], xs[0], dcal, cal, step_kw, avg_ms)
+                try:
+                    out["extra"]["two_streams"] = streams_extra(local_rank, shards, xs, cal, step_kw, units)
+                except Exception as e:  # noqa: BLE001
+                    out["extra"]["two_streams"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                    torch.cuda.empty_cache()
+            try:
+                out["extra"]["seasonal_field"] = seasonal_extra(hot, shards[0], xs[0], dcal, cal, step_kw, avg_ms)
+            except Exception as e:  # noqa: BLE001
+                out["extra"]["seasonal_field"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, args.seed)
+            try:
+                out["cpu_baseline"] = cpu_baseline(wl, args.seed)
+            except Exception as e:  # noqa: BLE001  (a host without room for the worker pool still gets its GPU line)
+                out["cpu_baseline"] = {"value": None, "unit": "Mcells*timesteps/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"[:300]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
