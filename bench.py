@@ -2,6 +2,7 @@
 """Benchmark of the preprocess_data hot path on MI355X.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          (plain command: starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,8 +11,10 @@ over one synthetic field that is already resident in HBM.  Metric (BASELINE.json
 (input timesteps), whole job.  Default workload `cfg3` = the configuration the metric is quoted on: the
 100-yr daily 1440x720 field (151 GB), resident as 8 overlapped latitude bands; N ranks take 8/N bands each
 (strong scaling, N in {1,2,4,8}).  `--workload cfg2` = the 10-yr field, one 720-row band per rank (weak
-scaling).  Bands are ingested with ws//2 overlap rows per interior side (marex_amd/dist.py); the only
-collective is an all-reduce of a few int64 scalars.
+scaling).  Bands are ingested with ws//2 overlap rows per interior side (marex_amd/dist.py); the collectives
+are a broadcast of the host-built tables (calendar, bin edges / centres, detrend model) from rank 0 before the
+timed region and an all-reduce of a few int64 scalars per step.  A rank with several bands runs them round-robin
+over `--streams` engines with a HIP stream each (marex_amd.dist.EngineSet, default 2): the product schedule.
 
 Prints ONE JSON line on rank 0.
 """
@@ -97,7 +100,7 @@ def cpu_baseline(wl, seed):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))  # a one-GPU box grants 16 cores of the host
+    cores = max(1, min(avail, 64))  # the cores this job may use (a one-GPU box grants a share of the host), at most 64 workers
     ny, nx = 32, 64
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(cores) as pool:
@@ -111,10 +114,13 @@ def cpu_baseline(wl, seed):
         "sample": f"NumPy oracle, {cores} processes x one {ny}x{nx} sub-grid of the same {wl['T']}-day workload each "
                   f"({dt:.1f} s wall incl. process start; {max(per):.1f} s slowest worker; host reports {os.cpu_count()} cores, "
                   f"{avail} usable)",
+        # the reference's own figure for its Dask path (docs/modules/detect.rst:729-731): not measured here
+        "reference_published": {"value": 7.9, "unit": "Mcells*timesteps/s", "cores": 255, "hardware": "unstated",
+                                "source": "reference docs/modules/detect.rst:729-731 (BASELINE.md 1)"},
     }
 
 
-def seasonal_extra(hot, shard, x, dcal, cal, step_kw, stationary_ms, amp=1.6, passes=3):
+def seasonal_extra(hot, shard, x, dcal, cal, step_kw, stationary_ms, amp=1.6, passes=3, wsp=None):
     """AFTER the timed region: the first band again with heteroscedastic noise added (amplitude follows the day of the year,
     so the p95 threshold of a cell swings over the year) -- the benchmark field has stationary noise, and the threshold
     kernel's band has to FOLLOW the thresholds; this line shows what a seasonal field costs.  Overwrites `x`."""
@@ -129,7 +135,8 @@ def seasonal_extra(hot, shard, x, dcal, cal, step_kw, stationary_ms, amp=1.6, pa
     for t0 in range(0, T, 2000):  # in slabs: no second field-sized temporary
         t1 = min(T, t0 + 2000)
         x[t0:t1] += amp * g[t0:t1, None] * torch.randn((t1 - t0, x.shape[1]), device=hot.device, generator=gen)
-    wsp = {}
+    wsp = {} if wsp is None else wsp
+    hot.ctx.timing_enable(True)
     for k in range(passes + 1):
         if k == 1:
             hot.sync()
@@ -146,44 +153,69 @@ def seasonal_extra(hot, shard, x, dcal, cal, step_kw, stationary_ms, amp=1.6, pa
     swing = (thr[:, ocean].max(dim=0).values - thr[:, ocean].min(dim=0).values).median().item() if bool(ocean.any()) else 0.0
     return {"what": f"band 0 with N(0, ({amp} * (1 + sin(2 pi doy / 365.25)) / 2)^2) added: per-launch kernel ms, {passes} passes",
             "median_threshold_swing_K": swing, "kernel_ms": ms,
-            "thresholds_ms_stationary": stationary_ms.get("thresholds"),
+            "thresholds_ms_stationary": stationary_ms.get("thresholds"), "mask_ms_stationary": stationary_ms.get("mask"),
             "n_extreme": int(r["n_true"].item())}
 
 
-def streams_extra(device, shards, xs, cal, step_kw, units, nstream=2, passes=3):
-    """AFTER the timed region: the same step with the bands alternating between `nstream` engines that own a HIP stream each, so
-    that kernels of neighbouring bands overlap (the HBM-heavy anomaly kernel of one band next to the issue-bound threshold
-    and mask kernels of another).  The headline number stays the single-stream one: its kernel durations are the ones the
-    roofline object and the rocprof summaries speak about."""
+def serial_extra(hot, shards, xs, dcal, step_kw, detrend, units, wsp, passes=2):
+    """AFTER the timed region: the same step with every band on ONE engine and ONE stream, kernels one after the other --
+    per-kernel HIP-event averages undisturbed by a neighbouring stream (the durations the rocprof summaries of a
+    `--streams 1` run show), and what the multi-stream schedule of the timed region buys."""
     import time as _time
 
     import torch
 
     from marex_amd.dist import shard_step
-    from marex_amd.engine import HotPath
 
-    engines = [HotPath(device, own_stream=True) for _ in range(nstream)]
-    dcals = [e.upload_calendar(cal) for e in engines]
-    wsps = [{} for _ in engines]
+    with torch.cuda.stream(hot.stream) if hot.stream is not None else _null():
+        shard_step(hot, shards, xs, dcal, workspace=wsp, detrend=detrend, **step_kw)
+        torch.cuda.synchronize()
+        hot.ctx.timing_enable(True)
+        hot.ctx.timing_reset()
+        t0 = _time.perf_counter()
+        for _ in range(passes):
+            _, local, _ = shard_step(hot, shards, xs, dcal, workspace=wsp, detrend=detrend, **step_kw)
+        torch.cuda.synchronize()
+        dt = (_time.perf_counter() - t0) / passes
+    ms = {}
+    for k in ("shifting", "detrend", "fixed", "tails", "thresholds", "mask", "transpose"):
+        tot, n = hot.ctx.timing_get(k)
+        if n:
+            ms[k] = tot / n
+    return {"what": f"every band on one engine and one HIP stream, {passes} passes", "ms_per_step": dt * 1e3, "value": units / dt,
+            "n_extreme": int(local[3].item()), "kernel_ms": ms}
 
-    def step():
-        outs = []
-        for i, (sh, x) in enumerate(zip(shards, xs)):
-            e = engines[i % nstream]
-            with torch.cuda.stream(e.stream):
-                outs.append(shard_step(e, [sh], [x], dcals[i % nstream], workspace=wsps[i % nstream], **step_kw)[1])
-        return outs
 
-    step()
-    torch.cuda.synchronize()
-    t0 = _time.perf_counter()
-    for _ in range(passes):
-        outs = step()
-    torch.cuda.synchronize()
-    dt = (_time.perf_counter() - t0) / passes
-    n_ext = int(sum(int(o[3].item()) for o in outs))
-    return {"what": f"bands alternate between {nstream} HIP streams on the one GPU, {passes} passes", "ms_per_step": dt * 1e3,
-            "value": units / dt, "n_extreme": n_ext}
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` as a plain command: this process -- which has made no GPU call -- starts N ranks of itself
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set them), lets rank 0 print the JSON line on
+    this process's stdout, and returns the first non-zero exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        code = pr.wait()
+        rc = rc or code
+    return rc
 
 
 def main():
@@ -193,29 +225,34 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=20240607)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MAREX_BENCH_STREAMS", "0")),
+                    help="engines (HIP streams) the bands of a rank alternate between; 0 = default (2, or 1 for a single band / "
+                         "the one-GPU rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements (seasonally drifting thresholds)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements (single-stream pass, seasonally drifting thresholds)")
     ap.add_argument("--hobday-path", default=None, choices=["tails", "bins"],
                     help="force the representation of the dayofyear histograms (default: the engine's own choice)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain command line: start the ranks from here (nothing in this process has touched the GPU)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
 
     from marex_amd import binning, calendar, synth
-    from marex_amd.dist import allreduce_step, plan_shards, shard_step
+    from marex_amd.dist import EngineSet, allreduce_step, broadcast_tables, plan_shards, shard_step
     from marex_amd.engine import HotPath
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     # MAREX_BENCH_BACKEND=gloo + MAREX_BENCH_ONE_GPU=1: rehearse the multi-rank path on a single-GPU box
     backend = os.environ.get("MAREX_BENCH_BACKEND", "nccl")
-    if os.environ.get("MAREX_BENCH_ONE_GPU"):
+    one_gpu = bool(os.environ.get("MAREX_BENCH_ONE_GPU"))
+    if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -243,15 +280,30 @@ def main():
         ny_total = wl["ny"] * world
     shard = shards[0]
 
-    hot = HotPath(local_rank)
-    hot.hobday_path = args.hobday_path
+    nstream = args.streams if args.streams > 0 else (1 if (len(shards) == 1 or one_gpu) else 2)
+    nstream = max(1, min(nstream, len(shards)))
+    eset = EngineSet(local_rank, nstream) if nstream > 1 else None
+    hot = eset.engines[0] if eset else HotPath(local_rank)
+    for e in (eset.engines if eset else [hot]):
+        e.hobday_path = args.hobday_path
     tm = calendar.daily_time_axis(wl["start"], T)
-    cal = calendar.build_calendar(tm, window_year_baseline=W)
+    # host-built tables: rank 0 makes them, every rank works from the broadcast copy
+    tables = None
+    if rank == 0:
+        cal0 = calendar.build_calendar(tm, window_year_baseline=W)
+        bt0 = binning.hobday_bins()
+        tables = calendar.plan_tables(cal0)
+        tables.update({"bins.edges": bt0.edges, "bins.centres": bt0.centres, "bins.precision": float(bt0.precision),
+                       "bins.max_anomaly": float(bt0.max_anomaly)})
+        if wl.get("detrend_orders"):
+            model0, pmodel0 = calendar.detrend_model(calendar.decimal_year(tm), list(wl["detrend_orders"]), False)
+            tables.update({"detrend.model": model0, "detrend.pmodel": pmodel0})
+    tables = broadcast_tables(tables, src=0, device=torch.device("cuda", local_rank), host_collectives=backend != "nccl")
+    cal = calendar.plan_from_tables(tables)
+    bt = binning.BinTable(edges=tables["bins.edges"], centres=tables["bins.centres"], precision=tables["bins.precision"],
+                          max_anomaly=tables["bins.max_anomaly"])
+    detrend = (tables["detrend.model"], tables["detrend.pmodel"]) if "detrend.model" in tables else None
     dcal = hot.upload_calendar(cal)
-    bt = binning.hobday_bins()
-    detrend = None
-    if wl.get("detrend_orders"):
-        detrend = calendar.detrend_model(calendar.decimal_year(tm), list(wl["detrend_orders"]), False)
     xs = []  # resident input, one [T, cells_in] tensor per band, generated on the device before timing
     for sh in shards:
         if sh.gridded:
@@ -259,13 +311,17 @@ def main():
         else:
             tab = synth.make_tables(tm, 0, sh.cells_in, args.seed, unstructured=True)
         xs.append(hot.synth_field(tab, cell_base=sh.cell_base))
+    torch.cuda.synchronize()
 
     workspace = {}  # output buffers are allocated once and reused: no allocator traffic in the timed loop
 
     step_kw = dict(W=W or 15, S=wl["S"], bins=bt, q=wl["pct"] / 100.0, wd=wl["wd"], ws=wl["ws"], nx=nx)
 
     def step():
-        r, local, mx = shard_step(hot, shards, xs, dcal, workspace=workspace, detrend=detrend, **step_kw)
+        if eset is not None:
+            r, local, mx = shard_step(eset, shards, xs, cal, detrend=detrend, **step_kw)
+        else:
+            r, local, mx = shard_step(hot, shards, xs, dcal, workspace=workspace, detrend=detrend, **step_kw)
         if world > 1:
             local, mx = allreduce_step(local, mx, host_collectives=backend != "nccl")
         return r, local, mx
@@ -276,24 +332,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    timers = eset if eset is not None else hot.ctx
     for _ in range(args.warmup):
         step()
     fence()
-    hot.ctx.timing_enable(True)
-    hot.ctx.timing_reset()
+    timers.timing_enable(True)
+    timers.timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         r, local, mx = step()
     fence()
     dt = time.perf_counter() - t0
-    hot.sync()
     tmax = torch.tensor([dt], dtype=torch.float64, device=hot.device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    kern = {k: hot.ctx.timing_get(k) for k in ("shifting", "detrend", "fixed", "tails", "thresholds", "mask", "transpose")}
+    kern = {k: timers.timing_get(k) for k in ("shifting", "detrend", "fixed", "tails", "thresholds", "mask", "transpose")}
     kern = {k: v for k, v in kern.items() if v[1]}
+    timers.timing_enable(False)
     path = r.get("path", "bins")
     summary = dict(zip(["n_ocean", "invalid_total", "invalid_cells", "n_extreme", "thr_too_low", "thr_too_high"],
                        [int(v) for v in local.tolist()]))
@@ -307,28 +364,32 @@ def main():
         T_out = cal.T_out
         cells_own_rank = sum(sh.cells_own for sh in shards)
         b_alg_rank = algorithmic_bytes(T, T_out, cells_own_rank)
-        # dominant kernel and its own algorithmic bytes PER LAUNCH (one launch = one band)
+        # dominant kernel and its own algorithmic bytes PER LAUNCH (one launch = one band, averaged over this rank's bands;
+        # DESIGN.md section 4)
+        cin = sum(sh.cells_in for sh in shards) / len(shards)
+        cown = cells_own_rank / len(shards)
         per_kernel_alg = {
-            "detrend": shard.cells_in * (4 * T + 4 * T + 1),
-            "fixed": shard.cells_in * (4 * T + 4 * T),
-            "shifting": shard.cells_in * (4 * T + 4 * T_out + 1),
-            "tails": shard.cells_in * 4 * T_out,            # its compulsory read (the tails it writes are internal)
-            "thresholds": shard.cells_own * 4 * 366,
-            "mask": shard.cells_own * (4 * T_out + T_out + 4 * 366),
-            "transpose": shard.cells_in * 8 * 366,
+            "detrend": cin * (4 * T + 4 * T + 1),
+            "fixed": cin * (4 * T + 4 * T),
+            "shifting": cin * (4 * T + 4 * T_out + 1),
+            "tails": cin * 4 * T_out,            # its compulsory read (the tails it writes are internal)
+            "thresholds": cown * 4 * 366,
+            "mask": cown * (4 * T_out + T_out + 4 * 366),
+            "transpose": cin * 8 * 366,
         }
         dom = max(kern, key=lambda k: kern[k][0])
         # HBM bytes of the dominant kernel from the committed PMC passes of this same command (profiles/)
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", f"r02_{args.workload}_traffic.json")
         knames = {"shifting": "k_shift_fast", "tails": "k_tail_extract", "transpose": "k_transpose", "detrend": "k_detrend", "fixed": "k_fixed_baseline",
                   "thresholds": "k_thr_tails" if path == "tails" else "k_thr_band",
                   "mask": "k_mask_tails" if path == "tails" else "k_mask_ge"}
         kname = knames[dom]
-        if world == 1 and os.path.exists(tfile):
-            for name, rec in json.load(open(tfile)).get("kernels", {}).items():
-                if name.startswith(kname):
-                    traffic = rec["hbm_bytes"]
+        for rnd in ("r03", "r02"):
+            tfile = os.path.join(ROOT, "profiles", f"{rnd}_{args.workload}_traffic.json")
+            if world == 1 and traffic is None and os.path.exists(tfile):
+                for name, rec in json.load(open(tfile)).get("kernels", {}).items():
+                    if name.startswith(kname):
+                        traffic = rec["hbm_bytes"]
         avg_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in kern.items()}
         achieved = per_kernel_alg[dom] / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] else 0.0
         out = {
@@ -349,10 +410,11 @@ def main():
                 "per_gpu_grid": [sum(sh.own1 - sh.own0 for sh in shards), nx] if ny_total else [sum(sh.cells_own for sh in shards)],
                 "global_grid": [ny_total, nx] if ny_total else [nx * world],
                 "bands_per_gpu": len(shards),
+                "streams_per_gpu": nstream,
                 "timesteps_in": T,
                 "timesteps_out": T_out,
-                "parallelism": (f"lat-band x{max(world, nbands)}, {halo} overlap rows, scalar all-reduce only" if ny_total
-                                else f"cell ranges x{world}, scalar all-reduce only"),
+                "parallelism": (f"lat-band x{max(world, nbands)}, {halo} overlap rows, tables broadcast from rank 0, scalar all-reduce per step" if ny_total
+                                else f"cell ranges x{world}, tables broadcast from rank 0, scalar all-reduce per step"),
                 "summary": summary,
                 "histogram_representation": path,
             },
@@ -366,6 +428,8 @@ def main():
                 "traffic": traffic,
                 "avg_launch_ms": avg_ms[dom],
                 "algorithmic_bytes_per_launch": per_kernel_alg[dom],
+                "timing": ("HIP events on each engine's stream over the timed region" +
+                           (f"; {nstream} streams share the GPU, so a launch's duration includes what its neighbours take" if nstream > 1 else "")),
             },
             "pipeline_roofline": {
                 "algorithmic_bytes_per_step_per_gpu": b_alg_rank,
@@ -376,19 +440,27 @@ def main():
             },
             "kernel_ms": avg_ms,
         }
-        if world == 1 and not args.no_extra and detrend is None:
-            # untimed additions: a failure here (say, no room left for the second engine's workspace) must not cost the line
+        if world == 1 and not args.no_extra:
+            # untimed additions: a failure here (say, no room left for another workspace) must not cost the line
             out["extra"] = {}
-            if len(shards) > 1:  # before the seasonal line: that one overwrites band 0
+            wsp0 = eset.workspaces[0] if eset is not None else workspace
+            if eset is not None:  # before the seasonal line: that one overwrites band 0
                 try:
-                    out["extra"]["two_streams"] = streams_extra(local_rank, shards, xs, cal, step_kw, units)
+                    se = serial_extra(hot, shards, xs, dcal, step_kw, detrend, units, wsp0)
+                    out["extra"]["single_stream"] = se
+                    if se["kernel_ms"].get(dom):
+                        a1 = per_kernel_alg[dom] / (se["kernel_ms"][dom] * 1e-3) / 1e9
+                        out["roofline"]["single_stream"] = {"avg_launch_ms": se["kernel_ms"][dom], "achieved": a1, "frac": a1 / HBM_PEAK_GBS}
                 except Exception as e:  # noqa: BLE001
-                    out["extra"]["two_streams"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                    out["extra"]["single_stream"] = {"error": f"{type(e).__name__}: {e}"[:300]}
                     torch.cuda.empty_cache()
-            try:
-                out["extra"]["seasonal_field"] = seasonal_extra(hot, shards[0], xs[0], dcal, cal, step_kw, avg_ms)
-            except Exception as e:  # noqa: BLE001
-                out["extra"]["seasonal_field"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if detrend is None:
+                try:
+                    base_ms = out["extra"].get("single_stream", {}).get("kernel_ms") or avg_ms
+                    with torch.cuda.stream(hot.stream) if hot.stream is not None else _null():
+                        out["extra"]["seasonal_field"] = seasonal_extra(hot, shards[0], xs[0], dcal, cal, step_kw, base_ms, wsp=wsp0)
+                except Exception as e:  # noqa: BLE001
+                    out["extra"]["seasonal_field"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(wl, args.seed)

@@ -183,18 +183,20 @@ class Context:
             self.py_opts[name] = int(value)
 
     def options(self, **opts):
-        """Context manager: ``with ctx.options(THR_DD=5, THR_TILE=16): ...`` -- the options are cleared afterwards."""
+        """Context manager: ``with ctx.options(THR_DD=5, THR_TILE=16): ...`` -- afterwards every option has the value it had
+        before (from ``set_option`` or seeded from ``MAREX_<NAME>``); options that were absent are cleared."""
         import contextlib
 
         @contextlib.contextmanager
         def _cm():
+            before = {k: self.py_opts.get(k) for k in opts}
             for k, v in opts.items():
                 self.set_option(k, v)
             try:
                 yield self
             finally:
-                for k in opts:
-                    self.set_option(k, None)
+                for k, old in before.items():
+                    self.set_option(k, old)
 
         return _cm()
 

@@ -167,6 +167,28 @@ def build_calendar(time=None, *, year=None, doy=None, window_year_baseline: Opti
     )
 
 
+_PLAN_ARRAYS = ("year", "doy", "tindex", "kept", "out_index", "rowb_index", "doy_start", "doy_rows", "doy_out")
+_PLAN_SCALARS = ("min_year", "n_cal_years", "first_valid_year_idx", "has_duplicates")
+
+
+def plan_tables(cal: CalendarPlan, prefix: str = "cal.") -> dict:
+    """A plan as a flat ``{name: array or scalar}`` dict -- what rank 0 broadcasts (marex_amd.dist.broadcast_tables)."""
+    out = {prefix + k: getattr(cal, k) for k in _PLAN_ARRAYS}
+    out.update({prefix + k: getattr(cal, k) for k in _PLAN_SCALARS})
+    if cal.time is not None:
+        out[prefix + "time"] = np.asarray(cal.time)
+    return out
+
+
+def plan_from_tables(tables: dict, prefix: str = "cal.") -> CalendarPlan:
+    """Inverse of :func:`plan_tables`: nothing is derived again, the received arrays ARE the plan."""
+    kw = {k: tables[prefix + k] for k in _PLAN_ARRAYS}
+    kw.update({k: tables[prefix + k] for k in _PLAN_SCALARS})
+    kw["min_year"], kw["n_cal_years"] = int(kw["min_year"]), int(kw["n_cal_years"])
+    kw["first_valid_year_idx"], kw["has_duplicates"] = int(kw["first_valid_year_idx"]), bool(kw["has_duplicates"])
+    return CalendarPlan(time=tables.get(prefix + "time"), **kw)
+
+
 def decimal_year(time) -> np.ndarray:
     """``year + days_elapsed / days_in_year`` as float64 (detect.py:2051-2057)."""
     import pandas as pd

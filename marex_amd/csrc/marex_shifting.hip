@@ -361,10 +361,15 @@ __device__ __forceinline__ void stb_u16(rsrc_t r, unsigned voff, int soff, int v
 }
 
 // 16-byte list stores: descriptor words built by hand (base, no stride, unbounded, raw dword format) so that the store can
-// be issued from inline assembly TOGETHER with the wait states it needs.  A 16-byte buffer store keeps reading its data
-// registers for a few cycles; with an SGPR soffset the compiler's hazard recogniser (ROCm 7.2) inserts nothing before the
-// next VALU write of those registers and its scheduler moves a separate s_nop away -- observed on gfx950: the first dword
-// of a chunk lost in lanes 12-15 of every 16.
+// be issued from inline assembly TOGETHER with the wait states it needs.  The hazard is the ISA manual's "VMEM store of more
+// than 64 bits of data followed by a VALU write of its vdata VGPRs" row of the manual-wait-state table (the programming
+// guide's rule for hand-issued dwordx3 / dwordx4 stores: end the asm string with s_nop 1 = two wait states,
+// cdna_hip_programming.md 5.7 item 1).  LLVM's hazard recogniser pads that row ONLY when soffset is not a register
+// (GCNHazardRecognizer::createsVALUHazard exempts MUBUF stores with an SGPR soffset), so for this store -- SGPR soffset, data
+// registers rewritten by the very next VALU instruction of the sort network -- nothing was inserted, and a separate s_nop
+// statement was scheduled away; observed on gfx950 / ROCm 7.2: the first dword of a chunk lost in lanes 12-15 of every 16.
+// The store and its wait states are therefore ONE asm statement: s_nop 2 = three wait states, one more than the table's two
+// (the row is documented for the no-soffset form; the extra state costs 4 cycles per 1-KiB store).
 typedef int tl_out_rsrc_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ tl_out_rsrc_t tl_out_make_rsrc(const void* base) {
     const unsigned long long b = (unsigned long long)base;

@@ -23,7 +23,7 @@
 // neighbouring dayofyears of one cell), v_pk_max_u16 / v_pk_min_u16 order both at once.
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)  // hipcc: host + device; a plain host compiler (tests/host/tail_networks_check.cpp): inline
 #define MAREX_HD __host__ __device__ __forceinline__
 #else
 #define MAREX_HD inline

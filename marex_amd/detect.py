@@ -233,10 +233,12 @@ class _FieldBlock:
         return _pipe(eng).upload(f.x[:, self.c0:self.c1], np.float32)
 
 
-def plan_blocks(field: _Field, eng, halo: int, per_cell_bytes: int, min_blocks: int = 1):
+def plan_blocks(field: _Field, eng, halo: int, per_cell_bytes: int, min_blocks: int = 1, engines=None):
     """Spatial blocks that fit the free HBM -- the device-side counterpart of the reference's Dask layout for this path
     (space chunked, ``time: -1``; detect.py:2617-2620, 785-792): latitude bands with ``halo`` overlap rows per interior
-    side on grids, cell ranges on meshes.  ``MAREX_BLOCKS=n`` forces the number of blocks (tests; tuning)."""
+    side on grids, cell ranges on meshes.  ``MAREX_BLOCKS=n`` forces the number of blocks (tests; tuning).
+    ``engines``: every engine that will hold a block at the same time; the budget of a block is then the smallest share any
+    of them gets -- 80 % of the free memory of its card divided by the number of engines listed on that card."""
     import os
 
     import torch
@@ -251,7 +253,10 @@ def plan_blocks(field: _Field, eng, halo: int, per_cell_bytes: int, min_blocks: 
     if eng.device.type != "cuda":
         return plan_shards(ny, nx, 1, halo)
     torch.cuda.empty_cache()
-    budget = int(torch.cuda.mem_get_info(eng.device)[0] * 0.8)
+    per_card: Dict[int, int] = {}
+    for e in (engines or [eng]):
+        per_card[e.device.index or 0] = per_card.get(e.device.index or 0, 0) + 1
+    budget = min(int(torch.cuda.mem_get_info(torch.device("cuda", card))[0] * 0.8) // k for card, k in per_card.items())
     n = max(1, min(int(min_blocks), ny if field.gridded else nx))
     while True:
         shards = plan_shards(ny, nx, n, halo)
@@ -606,6 +611,20 @@ def preprocess_data(
     share from its own host thread; nothing is exchanged between devices, the host stitches the Dataset.  The reference fans
     the same call out over a Dask cluster (helper.py:232-411).
 
+    Which kernel family a configuration takes (same results on every path; ``ctx.set_option`` / ``MAREX_<NAME>`` force the
+    other one, the bench line names the choice in ``config.histogram_representation``):
+
+    * anomaly, ``shifting_baseline``: ``k_shift_fast`` for a gap-free daily calendar with ``smooth_days_baseline`` 21 and
+      ``window_year_baseline`` in {3, 4, 5, 6, 7, 10, 13, 15}, or 11 / 15 days with 5 / 10 / 15 years, and the reference's
+      ``arange`` bin table; every other width, window, table, or calendar with gaps: the general ``k_shifting`` (about 4x slower);
+    * approximate Hobday thresholds: sorted key lists ("tails") when a dayofyear bucket holds at least 24 samples (24 output
+      years) or there is no spatial pooling -- ``k_thr_tails`` (tiles, pooling) or ``k_thr_cells`` (no pooling and a window of
+      at most 16 lists: 11 days x up to 15 years) -- otherwise (short buckets WITH pooling, e.g. 10 years of data) the bin matrix
+      and ``k_thr_band``; more than 128 samples per bucket, more than 511 bins or ``window_spatial_hobday`` > 7: the general
+      sliding-histogram kernel;
+    * mask: from the lists (``k_mask_tails``) on the tails path, from the bin matrix for buckets of at least 24 rows, else the
+      plain compare.
+
     Mirror of ``marEx.preprocess_data`` (detect.py:287-841).  Returns a Dataset with ``dat_anomaly``
     (float32), ``mask`` (bool), ``extreme_events`` (bool), ``thresholds`` (float32, dims
     ``(*space, dayofyear)`` for the approximate Hobday method, ``(dayofyear, *space)`` for the exact one,
@@ -637,7 +656,6 @@ def preprocess_data(
     )
 
     field = _Field(da, dimensions, coordinates)
-    eng = get_engine(device)
     bt = binning.hobday_bins(precision, max_anomaly) if method_percentile == "approximate" else None
     need_bins = bt if (method_extreme == "hobday_extreme" and method_percentile == "approximate") else None
     want_stn = bool(std_normalise) and method_anomaly == "detrend_harmonic"
@@ -654,7 +672,7 @@ def preprocess_data(
         engines.append(get_engine(dv, seen.get(dv, 0)))
         seen[dv] = seen.get(dv, 0) + 1
     eng = engines[0]
-    blocks = plan_blocks(field, eng, halo, int(per_cell * 1.25), min_blocks=len(engines))
+    blocks = plan_blocks(field, eng, halo, int(per_cell * 1.25), min_blocks=len(engines), engines=engines)
     single = len(blocks) == 1
     if not single:
         logger.info(f"Field processed in {len(blocks)} spatial blocks of <= {max(b.cells_in for b in blocks)} cells"

@@ -249,6 +249,8 @@ class HotPath:
             return None
         if self.hobday_path != "tails" and nd < 24 and ws > 1:
             return None  # short buckets with spatial pooling (cfg2): the bin-matrix kernels are the faster ones
+        if self.hobday_path != "tails" and q < 0.5:
+            return None  # the lists are read from the top: a low quantile walks most of every list (the public API stops at 60 %)
         return nd  # ws == 1: the per-cell threshold kernel (no tiles), any record length
 
     def _tail_buffers(self, nd: int, list_rows: int, Cn: int, wsp: Optional[dict]):
@@ -471,9 +473,12 @@ class HotPath:
         count_invalid: bool = True,
         wsp: Optional[dict] = None,
         sub: Optional[torch.Tensor] = None,
+        second_stage: bool = False,
     ) -> Dict[str, torch.Tensor]:
         """``x - nanmean_doy(x)`` for all timesteps (detect.py:2299-2397); ``dcal`` must be an untrimmed calendar.
-        ``sub`` ``[C]``: a per-cell value taken off ``x`` on load (the deferred residual mean of :meth:`detrend`)."""
+        ``sub`` ``[C]``: a per-cell value taken off ``x`` on load (the deferred residual mean of :meth:`detrend`).
+        ``second_stage``: called on the output of :meth:`detrend` with a shared workspace -- its mask / count buffers get
+        names of their own, so that the first stage's validation outputs (the RAW field's) survive."""
         self._bind_stream()
         T, Cn = x.shape
         cal = dcal.plan
@@ -482,8 +487,8 @@ class HotPath:
         if reference_period is not None:
             use = self._dev(((cal.year >= reference_period[0]) & (cal.year <= reference_period[1])).astype(np.uint8))
         out = self._buf(wsp, "anom", (T, Cn), torch.float32, self.device)
-        mask = self._buf(wsp, "mask", (Cn,), torch.uint8, self.device)
-        invalid = self._buf(wsp, "invalid", (Cn,), torch.int32, self.device)
+        mask = self._buf(wsp, "mask2" if second_stage else "mask", (Cn,), torch.uint8, self.device)
+        invalid = self._buf(wsp, "invalid2" if second_stage else "invalid", (Cn,), torch.int32, self.device)
         invalid.zero_()
         if bins is not None:
             edges = self.bin_tables(bins)[0]
@@ -574,7 +579,8 @@ class HotPath:
         nd = int(np.diff(cal.doy_start).max())
         if n_coef > 5 or nd > 128 or not self.ctx_opt("DETREND_FUSED", 1):
             d = self.detrend(x, model, pmodel, bool(force_zero_mean), None, count_invalid=True, wsp=wsp, defer_mean=True)
-            r = self.fixed_baseline(d["out"], dcal, reference_period, None, count_invalid=False, wsp=wsp, sub=d.get("mean"))
+            r = self.fixed_baseline(d["out"], dcal, reference_period, None, count_invalid=False, wsp=wsp, sub=d.get("mean"),
+                                    second_stage=True)
             return {"out": r["out"], "mask": d["mask"], "invalid_count": d["invalid_count"]}
         self._bind_stream()
         assert x.dtype == torch.float32 and x.is_contiguous() and cal.T == T and cal.T_out == T

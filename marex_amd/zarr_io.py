@@ -87,6 +87,21 @@ def _decompress_foreign(raw: bytes, nbytes: int) -> bytes:
     return bytes(out)
 
 
+def decode_fill_value(fv, dtype: np.dtype):
+    """Zarr v2 ``fill_value`` of the array metadata as a number (or None): floats may be spelled "NaN", "Infinity",
+    "-Infinity"; anything else that is not a number (base64 strings of structured / byte dtypes) is outside this reader."""
+    if fv is None:
+        return None
+    if isinstance(fv, str):
+        special = {"NaN": float("nan"), "Infinity": float("inf"), "-Infinity": float("-inf")}
+        if fv in special and dtype.kind == "f":
+            return special[fv]
+        raise DependencyError(f"unsupported fill_value {fv!r} for dtype {dtype}", details="only numbers, \"NaN\", \"Infinity\" and \"-Infinity\"")
+    if isinstance(fv, bool) or isinstance(fv, (int, float)):
+        return fv
+    raise DependencyError(f"unsupported fill_value {fv!r} for dtype {dtype}")
+
+
 def read_array(path: str) -> np.ndarray:
     """One Zarr v2 array directory -> NumPy array."""
     meta = json.load(open(os.path.join(path, ".zarray")))
@@ -97,10 +112,10 @@ def read_array(path: str) -> np.ndarray:
         raise DependencyError(f"unsupported compressor {comp.get('id')!r}")
     shape, chunks, dtype = tuple(meta["shape"]), tuple(meta["chunks"]), np.dtype(meta["dtype"])
     sep = meta.get("dimension_separator", ".")
-    fill = meta.get("fill_value")
+    fill = decode_fill_value(meta.get("fill_value"), dtype)
     out = np.empty(shape, dtype=dtype)
     if fill is not None:
-        out[...] = np.nan if fill == "NaN" else fill
+        out[...] = fill
     csize = int(np.prod(chunks)) * dtype.itemsize
     grid = [range((s + c - 1) // c) for s, c in zip(shape, chunks)]
     for idx in itertools.product(*grid):
@@ -245,8 +260,9 @@ def read_array_to_device(path: str, eng, lead: int | None = None):
     tdt = {"float32": torch.float32, "float64": torch.float64, "int32": torch.int32, "int64": torch.int64, "int8": torch.int8,
            "uint8": torch.uint8, "int16": torch.int16, "bool": torch.bool}[dtype.name]
     if missing:
-        fv = meta.get("fill_value")
-        fv = float("nan") if fv in ("NaN", None) and dtype.kind == "f" else (0 if fv is None else fv)
+        fv = decode_fill_value(meta.get("fill_value"), dtype)  # the host reader's decoding; no fill value: NaN for floats, else 0
+        if fv is None:
+            fv = float("nan") if dtype.kind == "f" else 0
         typed = out.view(tdt)
         for e0, e1 in missing:
             typed[e0:e1] = fv

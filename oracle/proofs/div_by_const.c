@@ -8,8 +8,8 @@
  * Prints, per divisor, the number of inputs where the two differ, split by class of a, plus the smallest and
  * largest |a| that differ.  NaN results compare equal to NaN results.
  *
- *   gcc -O2 -mfma -fopenmp -ffp-contract=off oracle/proofs/div_by_const.c -o oracle/_ref/div_by_const -lm
- *   oracle/_ref/div_by_const 1 64
+ *   gcc -O2 -mfma -fopenmp -ffp-contract=off oracle/proofs/div_by_const.c -o oracle/proofs/_build/div_by_const -lm
+ *   oracle/proofs/_build/div_by_const 1 64
  */
 #include <math.h>
 #include <stdint.h>

@@ -116,3 +116,50 @@ def test_two_rank_band_sharding_is_bit_identical(tmp_path):
     for p in parts:  # every rank holds the all-reduced scalars and the all-gathered thresholds of the whole grid
         assert list(p["summ"]) == [v["n_ocean"], v["total_invalid_in_ocean"], v["max_invalid"], int(ref["extreme_events"].sum())]
         assert np.array_equal(p["thr_all"], ref["thresholds"].T, equal_nan=True)
+
+
+def _bcast_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    from marex_amd.dist import broadcast_tables
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tables = None
+    if rank == 0:  # only the source builds anything
+        tm = calendar.daily_time_axis("1999-03-01", 7 * 365 + 40)
+        cal = calendar.build_calendar(tm, window_year_baseline=3)
+        bt = binning.hobday_bins()
+        model, pmodel = calendar.detrend_model(calendar.decimal_year(tm), [1, 2], True)
+        tables = calendar.plan_tables(cal)
+        tables.update({"bins.edges": bt.edges, "bins.centres": bt.centres, "bins.precision": 0.01, "detrend.model": model,
+                       "detrend.pmodel": pmodel, "empty": np.zeros((0, 3), dtype=np.float32)})
+    got = broadcast_tables(tables, src=0, host_collectives=True)
+    cal = calendar.plan_from_tables(got)
+    np.savez(os.path.join(out_dir, f"bc{rank}.npz"), year_plan=cal.year_plan(), kept=cal.kept, doy_rows=cal.doy_rows, time=cal.time.astype("int64"),
+             edges=got["bins.edges"], centres=got["bins.centres"], model=got["detrend.model"], pmodel=got["detrend.pmodel"],
+             scal=np.array([cal.min_year, cal.n_cal_years, cal.first_valid_year_idx, int(cal.has_duplicates), cal.T_out]),
+             prec=np.array([got["bins.precision"]]), empty_shape=np.array(got["empty"].shape))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tables_broadcast_from_rank_zero(tmp_path):
+    """calendar tables, bin edges / centres and the detrend model travel from rank 0 to the other ranks, which
+    derive nothing themselves; the received plan is the plan."""
+    world = 2
+    mp.spawn(_bcast_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    tm = calendar.daily_time_axis("1999-03-01", 7 * 365 + 40)
+    cal = calendar.build_calendar(tm, window_year_baseline=3)
+    bt = binning.hobday_bins()
+    model, pmodel = calendar.detrend_model(calendar.decimal_year(tm), [1, 2], True)
+    for r in range(world):
+        p = np.load(tmp_path / f"bc{r}.npz")
+        assert np.array_equal(p["year_plan"], cal.year_plan()) and np.array_equal(p["kept"], cal.kept)
+        assert p["kept"].dtype == np.bool_ and np.array_equal(p["doy_rows"], cal.doy_rows)
+        assert np.array_equal(p["time"], cal.time.astype("int64"))
+        assert p["edges"].dtype == np.float32 and p["edges"].tobytes() == bt.edges.tobytes() and p["centres"].tobytes() == bt.centres.tobytes()
+        assert p["model"].tobytes() == model.tobytes() and p["pmodel"].tobytes() == pmodel.tobytes()
+        assert list(p["scal"]) == [cal.min_year, cal.n_cal_years, cal.first_valid_year_idx, 0, cal.T_out]
+        assert float(p["prec"][0]) == 0.01 and list(p["empty_shape"]) == [0, 3]

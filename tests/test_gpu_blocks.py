@@ -110,6 +110,21 @@ def test_automatic_plan_is_one_block_when_the_field_fits(hot, monkeypatch):
     assert [s.own0 for s in shards[1:]] == [s.own1 for s in shards[:-1]]
 
 
+def test_block_budget_is_shared_by_the_engines_of_a_card(hot, monkeypatch):
+    """devices=[0, 0]: two engines hold a block each on the same card, so a block may take half of what one engine could."""
+    from marex_amd import detect
+
+    monkeypatch.delenv("MAREX_BLOCKS", raising=False)
+    da = gridded()
+    f = detect._Field(da, {"time": "time", "x": "lon", "y": "lat"}, {"time": "time", "x": "lon", "y": "lat"})
+    free = __import__("torch").cuda.mem_get_info(hot.device)[0]
+    per_cell = int(free * 0.75 / (13 * 14))  # the whole 13-row field fits one engine's budget ...
+    assert len(detect.plan_blocks(f, hot, 2, per_cell)) == 1
+    second = detect.get_engine(0, 1)
+    two = detect.plan_blocks(f, hot, 2, per_cell, min_blocks=2, engines=[hot, second])
+    assert len(two) >= 2 and max(s.cells_in for s in two) * per_cell <= free * 0.8 / 2  # ... but not half of it
+
+
 def test_pinned_pipe_round_trips_strided_arrays(hot):
     """marex_amd.transfer.PinnedPipe: chunked, multi-threaded staging in both directions, strided host views, several
     dtypes, more chunks than staging buffers, a row larger than a buffer."""

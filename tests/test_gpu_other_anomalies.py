@@ -109,3 +109,41 @@ def test_detrend_fixed_baseline_falls_back_beyond_five_terms(hot):
     got = hot.detrend_fixed_baseline(torch.from_numpy(x).to(hot.device), model, pmodel, True, hot.upload_calendar(cal), None)
     hot.sync()
     assert _same(got["out"].cpu().numpy(), exp)
+
+
+def test_two_stage_fallback_keeps_the_raw_validation_outputs_with_a_workspace(hot):
+    """detrend_fixed_baseline as two stages (DETREND_FUSED=0, or more than five terms) with a SHARED workspace: the second
+    stage's mask / count buffers are its own, so the returned mask and invalid counts are still those of the raw field."""
+    tm, x = _field("2001-01-01", 7 * 365 + 2, 4, 11)
+    x[100:130, 5] = np.nan   # an ocean cell with a gap
+    x[40, 7] = np.inf
+    cal = calendar.build_calendar(tm)
+    dcal = hot.upload_calendar(cal)
+    xd = torch.from_numpy(x).to(hot.device)
+    exp_mask, exp_inv = np.isfinite(x[0]), (~np.isfinite(x)).sum(axis=0)
+    assert exp_inv[5] == 30 and exp_inv[7] == 1
+    for orders, opts in (([1, 2], dict(DETREND_FUSED=0)), ([1, 2, 3, 4, 5], {})):
+        model, pmodel = calendar.detrend_model(calendar.decimal_year(tm), orders, False)
+        wsp = {}
+        with hot.ctx.options(**opts):
+            for _ in range(2):  # the second call reuses every buffer
+                got = hot.detrend_fixed_baseline(xd, model, pmodel, True, dcal, None, wsp=wsp)
+                hot.sync()
+                assert np.array_equal(got["mask"].cpu().numpy().astype(bool), exp_mask)
+                assert np.array_equal(got["invalid_count"].cpu().numpy(), exp_inv)
+        exp, _ = orc.fixed_baseline_anomaly(orc.detrend_anomaly(x, model, pmodel, True), cal, None)
+        assert _same(got["out"].cpu().numpy(), exp)
+
+
+def test_options_context_restores_previous_values(hot):
+    """ctx.options puts back what was set before it (set_option or MAREX_<NAME> seeds), it does not just clear."""
+    ctx = hot.ctx
+    assert "THR_DD" not in ctx.py_opts and "THR_TILE" not in ctx.py_opts
+    ctx.set_option("THR_DD", 40)
+    try:
+        with ctx.options(THR_DD=20, THR_TILE=16):
+            assert ctx.py_opts["THR_DD"] == 20 and ctx.py_opts["THR_TILE"] == 16
+        assert ctx.py_opts["THR_DD"] == 40 and "THR_TILE" not in ctx.py_opts
+    finally:
+        ctx.set_option("THR_DD", None)
+    assert "THR_DD" not in ctx.py_opts

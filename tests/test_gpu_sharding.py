@@ -65,3 +65,31 @@ def test_full_width_properties(hot):
     # mask == anomaly >= threshold[doy] recomputed on the host from the device outputs
     exp = a["dat_anomaly"] >= a["thr_doy_major"][cal.doy_out.astype(np.int64) - 1]
     assert np.array_equal(a["extreme_events"].astype(bool), exp)
+
+
+@pytest.mark.parametrize("nstream", [2, 3])
+def test_engine_set_round_robin_equals_one_engine(hot, nstream):
+    """The product schedule of a rank with several bands (marex_amd.dist.EngineSet: bands round-robin over engines that own a
+    HIP stream and a workspace each) gives the numbers of one engine working through the bands in order."""
+    from marex_amd.dist import EngineSet, shard_step
+
+    ny, nx, W, world = 40, 48, 5, 5
+    tm = calendar.daily_time_axis("2010-01-01", 10 * 365 + 3)
+    cal = calendar.build_calendar(tm, window_year_baseline=W)
+    dcal = hot.upload_calendar(cal)
+    bt = binning.hobday_bins()
+    shards = plan_shards(ny, nx, world, 2)
+    xs = [hot.synth_field(synth.make_tables(tm, sh.ny_in, nx, lat_range=(sh.in0, sh.in1, ny)), cell_base=sh.cell_base) for sh in shards]
+    kw = dict(W=W, S=21, bins=bt, q=0.95, wd=11, ws=5, nx=nx)
+    r1, local1, mx1 = shard_step(hot, shards, xs, dcal, workspace={}, **kw)
+    hot.sync()
+    es = EngineSet(0, nstream)
+    for _ in range(2):  # the second pass reuses the engines' workspaces
+        r2, local2, mx2 = shard_step(es, shards, xs, cal, **kw)
+    torch.cuda.synchronize()
+    assert local1.tolist() == local2.tolist() and mx1.tolist() == mx2.tolist()
+    assert int(local1[3]) > 0
+    for key in ("dat_anomaly", "extreme_events", "thr_doy_major", "mask"):  # the last band, whichever engine ran it
+        assert np.array_equal(r1[key].cpu().numpy(), r2[key].cpu().numpy(), equal_nan=True), key
+    tot, n = es.timing_get("shifting")
+    assert n == 0  # timing was never enabled
