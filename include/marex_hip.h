@@ -170,14 +170,16 @@ int marex_mask_ge_doy_bins_f32(marex_ctx* ctx, const float* anom, const uint16_t
  *                                   list_rows) lists of <= list_rows keys, each sorted descending, in NCH = 2 (list_rows
  *                                   <= 16) or 4 (<= 32) chunks of 8 keys.  list_rows = 32: marex_tail_extract_f32 on any
  *                                   anomaly field; list_rows = 15: what marex_shifting_baseline_tails_f32 emits itself
- *   aux    uint16, [366][C]         bits 0..9: number of keys of the bucket (= the samples the reference counts);
- *                                   bit 15: the bucket holds a non-NaN value >= edges[nb]
+ *   aux    uint32, [366][C]         bits 0..9: number of keys of the bucket (= the samples the reference counts);
+ *                                   bit 15: the bucket holds a non-NaN value >= edges[nb] (beyond the table: no key, but an
+ *                                   extreme of every finite threshold); bits 16..22 / 23..29: position of the first /
+ *                                   second such sample, bit 30: the second exists, bit 31: more than two
  * Rows are grouped by dayofyear through doy_start / doy_rows; max_bucket = rows of the largest dayofyear (<= 128).
  */
 int marex_tail_lists(int max_bucket, int list_rows);
 int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
                            const int32_t* doy_rows, int max_bucket, const float* edges, int nb, int list_rows, void* lists,
-                           uint16_t* aux);
+                           uint32_t* aux);
 
 /* The shifting-baseline anomaly stage of marex_shifting_baseline_f32 emitting TAILS (list_rows = 15) instead of the bin
  * matrix: the kernel sorts the keys of 15 output years at a time and writes them as one list per dayofyear; dayofyears its
@@ -186,21 +188,22 @@ int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int
 int marex_shifting_baseline_tails_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* year_plan,
                                       int n_cal_years, int W, int S, const float* edges, int nb, int64_t T_out, float* out,
                                       uint8_t* mask, int32_t* invalid_count, const int32_t* doy_start, const int32_t* doy_rows,
-                                      int max_bucket, void* lists, uint16_t* aux);
+                                      int max_bucket, void* lists, uint32_t* aux);
 
 /* Day-of-year thresholds from tails: same result as marex_hobday_thresholds_f32 (detect.py:2638-2732, 2465-2559: pooled
  * counts, count-interpolated quantile, NaN where the first kept anomaly is NaN, clamp and warning statistics), arguments as
  * there plus the tails and the anomaly field they belong to (`anom`, [T_out, C]: its row 0 is first_anom).
  * Needs nb <= 511, max_bucket <= 128 in at most 6 lists, ws <= 7, max_bucket*wd*ws*ws <= 65535 and C <= 2^24 (else -4: use
  * the bin-matrix entry point). */
-int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, int list_rows, const float* anom,
+int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lists, const uint32_t* aux, int list_rows, const float* anom,
                                       int64_t T_out, int64_t C, int ny, int nx, int max_bucket, const float* centres, int nb,
                                       double q, int wd, int ws, float lower_bound, float upper_bound, int row0, int row1,
                                       float* thr_doy_major, marex_thr_stats* stats);
 
 /* The extreme mask from tails: same result as marex_mask_ge_doy_f32 (detect.py:2003-2004, 833-835) without reading the
- * anomalies, except for samples in the threshold's own bin and for buckets holding values beyond the edge table. */
-int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, int list_rows, int max_bucket,
+ * anomalies, except for samples in the threshold's own bin and for buckets holding more than two values beyond the edge table
+ * (up to two are placed from the positions in aux). */
+int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, const uint32_t* aux, int list_rows, int max_bucket,
                                 const float* anom, const float* edges, int nb, const float* thr_doy_major,
                                 const int32_t* doy_start, const int32_t* doy_rows, int64_t T_out, int64_t C, int64_t c0,
                                 int64_t c1, uint8_t* extreme, unsigned long long* n_true);

@@ -50,6 +50,8 @@ struct marex_ctx {
     int* shift_info = nullptr;  // device, SHIFT_INFO_WORDS ints: which dayofyear chunks the fast anomaly kernel takes
     int* shift_plan = nullptr;  // device, [calendar years][92 chunks][8] ints: per-year records of the fast anomaly kernel
     size_t shift_plan_years = 0;
+    int* shift_lplan = nullptr;  // device, [calendar years + 2][92 chunks][8] ints: lean records of k_shift_lean
+    size_t shift_lplan_years = 0;
     unsigned char* thr_scratch = nullptr;  // device, per-(tile, day, lane) state bytes of the 1024-thread threshold tiles
     size_t thr_scratch_bytes = 0;
     unsigned char* detrend_scratch = nullptr;  // device, partial sums / coefficients / means of the detrend reductions

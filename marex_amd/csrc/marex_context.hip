@@ -56,6 +56,7 @@ extern "C" int marex_destroy(marex_ctx* ctx) {
     drain_timers(ctx);
     if (ctx->shift_info) (void)hipFree(ctx->shift_info);
     if (ctx->shift_plan) (void)hipFree(ctx->shift_plan);
+    if (ctx->shift_lplan) (void)hipFree(ctx->shift_lplan);
     if (ctx->thr_scratch) (void)hipFree(ctx->thr_scratch);
     if (ctx->detrend_scratch) (void)hipFree(ctx->detrend_scratch);
     if (ctx->morph_scratch) (void)hipFree(ctx->morph_scratch);

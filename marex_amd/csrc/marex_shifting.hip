@@ -1,6 +1,8 @@
 // marex_shifting.hip -- K_A: validation + smoothing + rolling climatology + anomaly + bins
 #include "marex_common.hip.h"
 #include "marex_tails.hip.h"
+#include <numeric>
+#include <utility>
 
 // ------------------------------------------------------------------------------------------------
 // K_A: shifting-baseline anomaly  (smoothing + rolling climatology + anomaly + bins + validation)
@@ -387,6 +389,52 @@ __device__ __forceinline__ void tl_out_store(tl_out_rsrc_t r, unsigned voff, uns
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 2" : : "v"(v), "v"(voff), "s"(r), "s"(soff_u) : "memory");
 }
 
+
+// LDS-DMA staging of the year's rows (`buffer_load_dword[x4] ... offen lds`: memory -> LDS with no VGPR destination, no
+// ds_write; addressing pinned by profiles/tools/lds_dma_probe.hip: LDS byte = M0 + lane * size, memory byte = descriptor base
+// + soffset + per-lane voffset).  One dwordx4 instruction moves FOUR rows of the stage (lanes 16 r .. 16 r + 15 take row r:
+// 16 lanes x 16 bytes = the 64 cells of a row), a dword instruction one row.  hipcc neither counts these loads nor knows
+// that M0 is written: every statement saves / restores M0, and the kernel waits for them with its own s_waitcnt vmcnt(N).
+// The same loads pointed at a scratch kilobyte of LDS are L2 PREFETCHES (nothing ever reads the bytes): the rows a workgroup
+// will stage a year from now are pulled out of HBM a year early, so the staging loads themselves are L2 hits.
+template <int RPW>
+struct DmaRows;  // G4 dwordx4 + G1 dword instructions cover the RPW rows of a wave
+#define MAREX_DMA_X4(m, so) "s_mov_b32 m0, " m "\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, " so " offen lds\n\t"
+#define MAREX_DMA_X1(m, so) "s_mov_b32 m0, " m "\n\ts_nop 0\n\tbuffer_load_dword %2, %3, " so " offen lds\n\t"
+template <>
+struct DmaRows<9> {  // S = 21: rows 0-3, 4-7, 8
+    static constexpr int NL = 3;
+    static __device__ __forceinline__ void issue(tl_out_rsrc_t r, unsigned voff4, unsigned voff1, unsigned l0, unsigned lstep, unsigned so0, unsigned rowb) {
+        unsigned keep;
+        const unsigned l1 = l0 + 4 * lstep, l2 = l0 + 8 * lstep, so1 = so0 + 4 * rowb, so2 = so0 + 8 * rowb;
+        asm volatile("s_mov_b32 %0, m0\n\t" MAREX_DMA_X4("%4", "%7") MAREX_DMA_X4("%5", "%8") MAREX_DMA_X1("%6", "%9") "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff4), "v"(voff1), "s"(r), "s"(l0), "s"(l1), "s"(l2), "s"(so0), "s"(so1), "s"(so2) : "memory");
+    }
+};
+template <>
+struct DmaRows<8> {  // S = 15 (30 rows staged as 32): rows 0-3, 4-7
+    static constexpr int NL = 2;
+    static __device__ __forceinline__ void issue(tl_out_rsrc_t r, unsigned voff4, unsigned voff1, unsigned l0, unsigned lstep, unsigned so0, unsigned rowb) {
+        unsigned keep;
+        const unsigned l1 = l0 + 4 * lstep, so1 = so0 + 4 * rowb;
+        asm volatile("s_mov_b32 %0, m0\n\t" MAREX_DMA_X4("%4", "%6") MAREX_DMA_X4("%5", "%7") "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff4), "v"(voff1), "s"(r), "s"(l0), "s"(l1), "s"(so0), "s"(so1) : "memory");
+    }
+};
+template <>
+struct DmaRows<7> {  // S = 11 (26 rows staged as 28): rows 0-3, 4, 5, 6
+    static constexpr int NL = 4;
+    static __device__ __forceinline__ void issue(tl_out_rsrc_t r, unsigned voff4, unsigned voff1, unsigned l0, unsigned lstep, unsigned so0, unsigned rowb) {
+        unsigned keep;
+        const unsigned l1 = l0 + 4 * lstep, l2 = l0 + 5 * lstep, l3 = l0 + 6 * lstep;
+        const unsigned so1 = so0 + 4 * rowb, so2 = so0 + 5 * rowb, so3 = so0 + 6 * rowb;
+        asm volatile("s_mov_b32 %0, m0\n\t" MAREX_DMA_X4("%4", "%8") MAREX_DMA_X1("%5", "%9") MAREX_DMA_X1("%6", "%10") MAREX_DMA_X1("%7", "%11") "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff4), "v"(voff1), "s"(r), "s"(l0), "s"(l1), "s"(l2), "s"(l3), "s"(so0), "s"(so1), "s"(so2), "s"(so3) : "memory");
+    }
+};
+#undef MAREX_DMA_X4
+#undef MAREX_DMA_X1
+
 #define SHIFT_INFO_WORDS 128  // [0..91] chunk handled by the fast kernel, [92] arange edges usable
 #define CLASSIFY_SPLIT 11      // threads per chunk in k_shift_classify (92 * 11 = 1012 <= 1024)
 
@@ -395,8 +443,13 @@ __device__ __forceinline__ void tl_out_store(tl_out_rsrc_t r, unsigned voff, uns
 // first dayofyear of the chunk's WORKGROUP (16 dayofyears) in the FOLLOWING year}: everything k_shift_fast needs per year
 // in ONE 32-byte scalar load, every field live (a dead field lets the register allocator recycle its SGPR and wait for
 // the load on the spot)
+// lplan != NULL (k_shift_lean, smoothing width reg_S): the lean records of that kernel (LeanRec, below) -- a year is REGULAR for a
+// chunk when all 4 dayofyears are present on consecutive timesteps, the workgroup's rows are staged (block inside the series,
+// the chunk where the block puts it), no smoothing window leaves the series and, in output years, the 4 samples sit at the same
+// position of their buckets.
 __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, const float* __restrict__ edges, int nb,
-                                 int want_bins, int enable, int* __restrict__ info, int4* __restrict__ fplan) {
+                                 int want_bins, int enable, int* __restrict__ info, int4* __restrict__ fplan, long T, long C,
+                                 int reg_S, int4* __restrict__ lplan, const int* __restrict__ doy_start) {
     __shared__ int s_edges_ok;
     const int t = threadIdx.x;
     int eok = 1;
@@ -454,6 +507,41 @@ __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, 
         if (!ok) atomicAnd(&s_ok[chunk], 0);
     }
     __syncthreads();
+    if (chunk < 92 && lplan && reg_S > 0) {  // lean records of years -1 .. n_cal
+        const int H = reg_S / 2, NPAIR = (reg_S + 3) / 2, NROWS = 4 * ((reg_S + 15 + 3) / 4);
+        const int d0 = chunk * 4, blk16 = (chunk >> 2) * 16;
+        for (int yy = sub - 1; yy <= n_cal; yy += CLASSIFY_SPLIT) {
+            int flags = 0, tbv = -1, pos = 0;
+            long long xoff = 0, ooff = 0;
+            if (yy + 1 >= 0 && yy + 1 < n_cal) {  // next year's rows of the workgroup: rows tb - H .. tb - H + NROWS - 1
+                const int tbn = year_plan[(size_t)(yy + 1) * NDOY + blk16].x;
+                if (tbn >= H && (long)tbn - H + NROWS <= T) {
+                    flags |= 4;  // LR_STAGE_NEXT
+                    xoff = (long long)(tbn - H) * C * 4;
+                }
+            }
+            if (yy >= 0 && yy < n_cal) {
+                int4 e[4];
+                for (int i = 0; i < 4; ++i) e[i] = (d0 + i < NDOY) ? year_plan[(size_t)yy * NDOY + d0 + i] : make_int4(-1, -1, -1, 0);
+                tbv = year_plan[(size_t)yy * NDOY + blk16].x;
+                int reg = d0 + 3 < NDOY && e[0].x >= 0 && e[1].x >= 0 && e[2].x >= 0 && e[3].x >= 0;
+                reg = reg && tbv >= H && (long)tbv - H + NROWS <= T && e[0].x == tbv + 4 * (chunk & 3);
+                reg = reg && e[0].x - H >= 0 && (long)e[0].x - H + 2 * NPAIR <= T;
+                for (int i = 1; i < 4; ++i) reg = reg && e[i].x == e[0].x + i && ((e[0].y >= 0) == (e[i].y >= 0));
+                if (e[0].y >= 0) {
+                    flags |= 2;  // LR_OUT
+                    ooff = (long long)e[0].y * C * 4;
+                    pos = e[0].z - doy_start[d0];
+                    reg = reg && pos >= 0 && pos < TAIL_MAX_BUCKET;
+                    for (int i = 1; i < 4; ++i) reg = reg && e[i].y == e[0].y + i && e[i].z - doy_start[d0 + i] == pos;
+                }
+                if (reg) flags |= 1;  // LR_REG
+            }
+            int4* r = lplan + ((size_t)(yy + 1) * 92 + chunk) * 2;
+            r[0] = make_int4(flags, tbv, (int)(unsigned)(xoff & 0xFFFFFFFFll), (int)(unsigned)((unsigned long long)xoff >> 32));
+            r[1] = make_int4((int)(unsigned)(ooff & 0xFFFFFFFFll), (int)(unsigned)((unsigned long long)ooff >> 32), pos, 0);
+        }
+    }
     if (t < 92) info[t] = s_ok[t] && s_edges_ok;
 }
 
@@ -467,13 +555,13 @@ __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, 
 #define SHIFT_LIST 15   // output years per emitted list (15 x 2 pairs x 256 B x 4 waves + one 9-KiB stage = 39 KiB: 4 workgroups per CU)
 struct TailOut {
     uint4* lists;              // [366][NPER][2][C] chunks
-    unsigned short* aux;       // [366][C]
+    unsigned* aux;             // [366][C] count | samples beyond the table (marex_tails.hip.h)
     const int* doy_start;      // [367] first bin-matrix row of every dayofyear (key positions = row - doy_start)
     int nper;
     unsigned long long* dbg;   // debug counters (-DSHIFT_STAMPS builds: phase timers)
 };
 
-template <int W, bool TAILS, int S = 21>
+template <int W, bool TAILS, int S = 21, bool DMA = false>
 __global__ void __launch_bounds__(256)
 k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict__ fplan, int n_cal,
              const int* __restrict__ info, int write_clim, const float* __restrict__ edges, int nb, long T_out, float* __restrict__ out, unsigned short* __restrict__ bins, unsigned char* __restrict__ mask,
@@ -492,7 +580,12 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     static_assert((S & 1) == 1 && S >= 5 && S <= 25, "k_shift_fast: odd smoothing widths 5..25");
     constexpr int H = S / 2, NPAIR = (S + 3) / 2, NST = S + 15, RPW = (NST + 3) / 4;  // RPW: rows each wave stages per year
     constexpr int NSTAGE = TAILS ? 1 : 2;
-    __shared__ float stage[NSTAGE][NST * 64];
+    // DMA (TAILS only): the rows go from memory straight into the stage (DmaRows above) and the rows of the year AFTER next are
+    // prefetched into the L2 through a scratch kilobyte; every wave issues the same instructions, so the stage has 4 RPW rows
+    static_assert(!DMA || TAILS, "k_shift_fast: LDS-DMA staging is built for the single stage buffer of the TAILS variant");
+    constexpr int NROWS = DMA ? 4 * RPW : NST;
+    __shared__ float stage[NSTAGE][NROWS * 64];
+    __shared__ float pf_dump[DMA ? 256 : 1];
     __shared__ unsigned newkeys[TAILS ? 4 : 1][2][TAILS ? SHIFT_LIST : 1][64];  // [wave][pair of dayofyears][year slot][lane]
 #ifdef SHIFT_PAD  // experiment: extra LDS (floats) to lower the number of resident workgroups
     __shared__ float lds_pad[SHIFT_PAD];
@@ -532,7 +625,7 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     if (chunk == 0 && mine && mask && active) mask[c] = finite_f(x[c]) ? 1 : 0;
     // rows tb-H .. tb+15+H (tb = timestep of the workgroup's first dayofyear in that year) can be staged when they
     // all lie inside the series; this wave loads rows RPW*wave .. RPW*wave+RPW-1 of them (the last wave fewer when 4 RPW > NST)
-    auto stage_ok = [&](int tb) { return tb >= H && (long)tb + 16 + H <= T; };
+    auto stage_ok = [&](int tb) { return tb >= H && (long)tb - H + NROWS <= T; };
     auto stage_load = [&](int tb, float (&nx)[RPW]) {
         const rsrc_t rs = make_rsrc(x + (size_t)(tb - H + RPW * wave) * C);
 #pragma unroll
@@ -546,14 +639,40 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     };
     int tb_cur = fplan[(size_t)(bc * 4) * 2].x;
     int tb_n1 = prec[1].w;  // year 1 (record of year 0), known one iteration ahead of its row prefetch
-    {
+    // DMA: lane offsets of the 4-row instruction (lane 16 r + s: row r, cells 4 s .. 4 s + 3 of the group; a segment beyond C --
+    // C is a multiple of 4 on this path -- reads the last four cells instead: those lanes are masked wherever they store)
+    typedef __attribute__((address_space(3))) float lds_f32;
+    unsigned dma_voff4 = 0, dma_lds = 0, dma_dump = 0;
+    if (DMA) {
+        const long c4 = (long)cg * 64 + (lane & 15) * 4;
+        dma_voff4 = (unsigned)(lane >> 4) * (unsigned)rowb + (unsigned)(c4 + 4 <= C ? c4 : C - 4) * 4u;
+        dma_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_f32*)&stage[0][(RPW * wave) * 64]);
+        dma_dump = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_f32*)&pf_dump[0]);
+    }
+    // rows 365 days after a staged block lie inside the series (the prefetch of the year after next: 365 or 366 days on, the
+    // difference is one row of 4 RPW)
+    auto pf_ok = [&](int tb) { return (long)tb + 365 - H + NROWS <= T; };
+    // stage the rows of the year whose workgroup block starts at timestep tb (+ prefetch the same rows 365 days on)
+    auto dma_year = [&](int tb, bool pf) {
+        const tl_out_rsrc_t rs = tl_out_make_rsrc(x + (size_t)(tb - H + RPW * wave) * C);
+        DmaRows<RPW>::issue(rs, dma_voff4, voff, dma_lds, 256u, 0u, (unsigned)rowb);
+        if (pf) DmaRows<RPW>::issue(rs, dma_voff4, voff, dma_dump, 0u, 365u * (unsigned)rowb, (unsigned)rowb);
+    };
+    bool dma_pf = false;
+    if (DMA) {
+        if (stage_ok(tb_cur)) {
+            dma_year(tb_cur, pf_ok(tb_cur));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");
+    } else {
         float nx[RPW];
         if (stage_ok(tb_cur)) {
             stage_load(tb_cur, nx);
             stage_store(0, nx);
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     // History of dayofyears (0,1) and (2,3) as register lines.  The year loop is unrolled by two: the first year of a
     // pair reads entries [0, W) and appends at [W], the second reads [1, W] and appends at [W+1], then the line moves
@@ -595,7 +714,7 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                             w[i] = h == 0 ? ((a & 0xFFFFu) | (b << 16)) : ((a >> 16) | (b & 0xFFFF0000u));
                         }
                         const int li = __builtin_amdgcn_readfirstlane((di * tails.nper + t_list) * 2 + jj);
-                        tl_out_store(rl, lvoff, (unsigned)li * (unsigned)C * 16u, w);
+                        if (!DMA || active) tl_out_store(rl, lvoff, (unsigned)li * (unsigned)C * 16u, w);
                     }
                 }
             }
@@ -616,11 +735,13 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
         SSTAMP(tsA);
         const int4 pA = nA, pB = nB;  // {first timestep, first output row, dayofyears present, row 0}, {rows 1..3, next tb}
         const int tb = tb_cur;
-        float nx[RPW];
+        float nx[RPW];  // (unused with DMA)
         // next year's rows, one iteration ahead (its first timestep arrived during the previous iteration)
         const bool stage_next = y + 1 < n_cal && stage_ok(tb_n1) && !(SHIFT_EXP & 2);
-        if (stage_next) stage_load(tb_n1, nx);
+        if (!DMA && stage_next) stage_load(tb_n1, nx);
         v2f smA = splat2(qnan), smB = splat2(qnan);
+        v2f oA = splat2(0.f), oB = splat2(0.f);  // DMA: this year's output rows, stored at the end
+        int o_n = 0;
         v2f xp[NPAIR];  // xp[m] = rows (r0 + 2m, r0 + 2m + 1), r0 = first timestep - H
         const bool staged = mine && pA.z > 0 && stage_ok(tb) && pA.x == tb + 4 * wave;
         if (staged) {
@@ -635,6 +756,11 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
             // single stage buffer: every wave has its rows in registers before anyone overwrites the buffer with the next
             // year's (LDS traffic only: no vector-memory wait here, the row prefetch stays in flight)
             if (!(SHIFT_EXP & 1)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (DMA && stage_next) {
+                // the stage is free: next year's rows on their way into it, the rows of the year after next on their way into the L2
+                dma_pf = y + 2 < n_cal && pf_ok(tb_n1);
+                dma_year(tb_n1, dma_pf);
+            }
         }
         else asm volatile("" ::: "memory");
         // scalar loads of the years to come go out HERE, after the wait for the staged rows: they are in flight during the
@@ -744,12 +870,18 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                     if (!(climB.y == climB.y)) climB.y = acc[3] / (float)n[3];
                 }
                 const v2f aA = xcA - climA, aB = xcB - climB;
+                if (DMA) {  // stored at the end of the year, behind the wait for the staged rows (the stores stay younger than it)
+                    oA = write_clim ? climA : aA;
+                    oB = write_clim ? climB : aB;
+                    o_n = pA.z;
+                } else {
                 const rsrc_t ro = make_rsrc(out + (size_t)pA.y * C);
                 if (!(SHIFT_EXP & 4) || aA.x == 12345.678f) {
                     stb_f32(ro, voff, 0, write_clim ? climA.x : aA.x);
                     if (has1) stb_f32(ro, voff, rowb, write_clim ? climA.y : aA.y);
                     if (has2) stb_f32(ro, voff, 2 * rowb, write_clim ? climB.x : aB.x);
                     if (has3) stb_f32(ro, voff, 3 * rowb, write_clim ? climB.y : aB.y);
+                }
                 }
                 if ((do_bins || TAILS) && (!(SHIFT_EXP & 8) || aB.y == 12345.678f)) {
                     // np.digitize(a, edges) - 1 on the arange table (contract C4): the guess, biased down, is the
@@ -791,9 +923,14 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
                         // not counted although it is a number: a value at or beyond the last edge (next to never: one test
                         // of the largest of the four, maxNum skips NaN)
                         const float mx = fmaxf(fmaxf(aA.x, has1 ? aA.y : aA.x), fmaxf(has2 ? aB.x : aA.x, has3 ? aB.y : aA.x));
-                        if (__builtin_amdgcn_ballot_w64(mx >= e_last) != 0) {
-                            t_ovfA |= ((aA.x >= e_last) ? 1u : 0u) | ((has1 && aA.y >= e_last) ? 0x10000u : 0u);
-                            t_ovfB |= ((has2 && aB.x >= e_last) ? 1u : 0u) | ((has3 && aB.y >= e_last) ? 0x10000u : 0u);
+                        if (__builtin_amdgcn_ballot_w64(mx >= e_last) != 0) {  // their positions (the first two) go into the aux word
+                            unsigned s0 = t_ovfA & 0xFFFFu, s1 = t_ovfA >> 16, s2 = t_ovfB & 0xFFFFu, s3 = t_ovfB >> 16;
+                            if (aA.x >= e_last) s0 = tail_ovf_add(s0, (unsigned)(pA.w - t_ds0));
+                            if (has1 && aA.y >= e_last) s1 = tail_ovf_add(s1, (unsigned)(pB.x - t_ds1));
+                            if (has2 && aB.x >= e_last) s2 = tail_ovf_add(s2, (unsigned)(pB.y - t_ds2));
+                            if (has3 && aB.y >= e_last) s3 = tail_ovf_add(s3, (unsigned)(pB.z - t_ds3));
+                            t_ovfA = s0 | (s1 << 16);
+                            t_ovfB = s2 | (s3 << 16);
                         }
                         ++t_slot;  // flushed between years (main loop), outside this body's register pressure
                     } else {
@@ -808,8 +945,27 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
         rA[J + W] = smA;  // year y joins the history
         rB[J + W] = smB;
         SSTAMP(tsC);
+        if (DMA) {
+            // the staged rows of next year have landed (everything older than the prefetch loads issued behind them), then the
+            // anomaly stores, then the barrier that lets every wave read the stage
+            if (stage_next) {
+                if (dma_pf)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DmaRows<RPW>::NL) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (o_n > 0 && active) {  // lanes beyond C hold other cells' rows on this path: they store nothing
+                const rsrc_t ro = make_rsrc(out + (size_t)pA.y * C);
+                stb_f32(ro, voff, 0, oA.x);
+                if (o_n > 1) stb_f32(ro, voff, rowb, oA.y);
+                if (o_n > 2) stb_f32(ro, voff, 2 * rowb, oB.x);
+                if (o_n > 3) stb_f32(ro, voff, 3 * rowb, oB.y);
+            }
+            asm volatile("s_barrier" ::: "memory");
+        } else {
         if (stage_next) stage_store((y + 1) & 1, nx);
         if (!(SHIFT_EXP & 1)) __syncthreads();
+        }
 #ifdef SHIFT_STAMPS
         const unsigned long long tsD = __builtin_amdgcn_s_memtime();
         st_top += tsB - tsA;
@@ -838,7 +994,7 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
             const unsigned ov[4] = {t_ovfA & 0xFFFFu, t_ovfA >> 16, t_ovfB & 0xFFFFu, t_ovfB >> 16};
 #pragma unroll
             for (int di = 0; di < 4; ++di)
-                if (d0 + di < NDOY) tails.aux[(size_t)(d0 + di) * C + c] = (unsigned short)(cn[di] | (ov[di] ? 0x8000u : 0u));
+                if (d0 + di < NDOY) tails.aux[(size_t)(d0 + di) * C + c] = tail_aux_word(cn[di], ov[di]);
         }
     }
     if (invalid_count && active && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
@@ -851,6 +1007,447 @@ k_shift_fast(const float* __restrict__ x, long T, long C, const int4* __restrict
     }
 #endif
 }
+
+// ------------------------------------------------------------------------------------------------
+// K_A lean: k_shift_fast<W, TAILS> rewritten around its instruction count.  The fast kernel runs at the issue limit of the
+// SIMDs (223 vector + 110 scalar + 22 branch instructions per wave, year and 4 dayofyears; staging the rows by LDS-DMA with an
+// L2 prefetch a year ahead changed nothing), so this kernel removes instructions:
+//   * REGULAR years -- flagged per (year, chunk) by k_shift_classify: all 4 dayofyears present, rows staged, no window leaving
+//     the series, the 4 samples at the same bucket position -- take a straight-line body that never looks at the calendar;
+//     every other year (first days of the series, the leap-day chunk, the trailing partial year) takes the general body of
+//     k_shift_fast;
+//   * (tried and dropped: a CIRCULAR history line, a run of regular years unrolled W times so that no register ever moves -- the
+//     26 v_mov per year of the shift line gone, but 15 copies of the year body, with their rare blocks and the list flush inline,
+//     are 180 KB of code and spill: 45.6 ms against 11.8 ms on a 100-yr band.  The line of W + 2 entries that moves by two
+//     every two years stays.)
+//   * everything about the calendar is resolved ONCE, on the device, into a lean record per (year, chunk) (flags, the byte
+//     offsets of next year's staged rows and of this year's output rows, the bucket position): the straight-line body adds two
+//     64-bit offsets and tests three flag bits where the fast kernel spends ~110 scalar instructions per year on records,
+//     range checks and 64-bit address arithmetic;
+//   * rows are staged by LDS-DMA (3 instructions per wave and year instead of 9 loads + 9 ds_write) and read from the stage in
+//     two halves through the same registers.
+//   (Also tried: lane masks of the class / range tests compared with ONE land mask by scalar instructions, scalar counters for
+//   the uniform part -- 30 vector instructions fewer, 31 scalar instructions more per year, same time.)
+// Same arithmetic, same bits: tests run both kernels against the oracle and against each other (SHIFT_LEAN=0 selects the fast one).
+// ------------------------------------------------------------------------------------------------
+template <typename F, int... Is>
+__device__ __forceinline__ void unroll_steps_impl(F& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void unroll_steps(F&& f) {
+    unroll_steps_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// lean records (k_shift_classify with reg_S > 0): lplan[((y + 1) * 92 + chunk) * 2 + {0, 1}], y = -1 .. n_cal (the first and the
+// last year are padding: the prologue reads "year -1" for the staging of year 0, the prefetch of the last year's successor needs
+// no range check).  A = {flags, first timestep of the workgroup's 16 dayofyears this year (-1: none), byte offset lo / hi of row
+// (that timestep of NEXT year - H) in x}, B = {byte offset lo / hi of this year's first output row of the chunk, bucket position
+// of its 4 samples, 0}.  Everything the straight-line body needs to know about the calendar is here, resolved on the device once.
+#define LR_REG 1         // regular year for this chunk (see k_shift_classify)
+#define LR_OUT 2         // an output year
+#define LR_STAGE_NEXT 4  // next year's rows of the workgroup can be staged (the block lies inside the series)
+
+template <int W, int S>
+__global__ void __launch_bounds__(256, 4)  // four workgroups per CU: at most 128 VGPRs
+k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__ fplan, const int4* __restrict__ lplan, int n_cal,
+             const int* __restrict__ info, const float* __restrict__ edges, int nb, float* __restrict__ out,
+             unsigned char* __restrict__ mask, int* __restrict__ invalid_count, int ncg, int nblk, TailOut tails) {
+    int cg, bc;
+    if (!xcd_swizzle(blockIdx.x, ncg, nblk, cg, bc)) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int chunk = bc * 4 + wave;
+    static_assert((S & 1) == 1 && S >= 5 && S <= 25, "k_shift_lean: odd smoothing widths 5..25");
+    constexpr int H = S / 2, NPAIR = (S + 3) / 2, NST = S + 15, RPW = (NST + 3) / 4;
+    // the rows of a year go from memory straight into the stage by LDS-DMA (DmaRows above: three instructions per wave instead of
+    // nine loads and nine ds_write, and no registers held by a prefetched year); every wave issues the same instructions, so
+    // the stage has 4 RPW rows
+    constexpr int NROWS = 4 * RPW;
+    __shared__ float stage[NROWS * 64];
+    __shared__ unsigned newkeys[4][2][SHIFT_LIST][64];  // [wave][pair of dayofyears][year slot][lane]
+    const bool mine = chunk < 92 && info[chunk] != 0;  // wave-uniform; the other waves only help staging
+    const int d0 = mine ? chunk * 4 : 0;
+    const int c = cg * 64 + lane;
+    const bool active = c < C;
+    const unsigned cidx = active ? (unsigned)c : (unsigned)(C - 1);
+    const unsigned voff = cidx * 4u;
+    const int rowb = C * 4;
+    const float e_first = edges[1], e_delta = edges[2] - edges[1], e_last = edges[nb];
+    const float inv_width = (float)(nb - 1) / (e_last - e_first);
+    constexpr float Sf = (float)S;
+    const float yS = 1.0f / Sf;
+    const float Wf = (float)W;
+    const float yW = 1.0f / Wf;
+    const float nbm1f = (float)(nb - 1);
+    const float c0 = (1.0f - e_first * inv_width) - 0.0078125f;
+    const float qnan = nan_f();
+    if (chunk == 0 && mine && mask && active) mask[c] = finite_f(x[c]) ? 1 : 0;
+
+    // lane offsets of the 4-row instruction (lane 16 r + s: row r, cells 4 s .. 4 s + 3 of the group; a segment beyond C -- C is a
+    // multiple of 4 here -- reads the last four cells instead: those lanes are masked wherever they store)
+    typedef __attribute__((address_space(3))) float lds_f32;
+    const int c4 = cg * 64 + (lane & 15) * 4;
+    const unsigned dma_voff4 = (unsigned)(lane >> 4) * (unsigned)rowb + (unsigned)(c4 + 4 <= C ? c4 : C - 4) * 4u;
+    const unsigned dma_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_f32*)&stage[(RPW * wave) * 64]);
+    const char* xw = reinterpret_cast<const char*>(x) + (size_t)(RPW * wave) * (size_t)C * 4;  // this wave's share of a staged block
+    auto dma_rows = [&](int lo, int hi) __attribute__((always_inline)) {
+        const unsigned long long off = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+        DmaRows<RPW>::issue(tl_out_make_rsrc(xw + off), dma_voff4, voff, dma_lds, 256u, 0u, (unsigned)rowb);
+    };
+    constexpr int LSTRIDE = 92 * 2;  // int4 per year of lean records
+    const int4* lr_next = lplan + (size_t)chunk * 2;  // "year -1"
+    {
+        const int4 pre = lr_next[0];
+        if (pre.x & LR_STAGE_NEXT) {
+            dma_rows(pre.z, pre.w);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");
+        lr_next += LSTRIDE;
+    }
+    int4 nA = lr_next[0], nB = lr_next[1];  // year 0
+    lr_next += LSTRIDE;
+
+    // history of dayofyears (0,1) and (2,3) as register lines; the year loop is unrolled by two: the first year of a pair reads
+    // entries [0, W) and appends at [W], the second reads [1, W] and appends at [W + 1], then the line moves down by two
+    v2f hA[W + 2], hB[W + 2];
+#pragma unroll
+    for (int j = 0; j < W + 2; ++j) hA[j] = hB[j] = splat2(qnan);
+    int n_invalid = 0;
+    unsigned t_cntA = 0, t_cntB = 0, t_ovfA = 0, t_ovfB = 0;
+    int t_slot = 0, t_list = 0;
+    int n_lean = 0, n_gen = 0;  // years of this wave that took the straight-line / the general body (debug counters 6 / 7)
+    auto tails_flush = [&]() __attribute__((always_inline)) {
+        const tl_out_rsrc_t rl = tl_out_make_rsrc(tails.lists + (size_t)d0 * tails.nper * 2 * (size_t)C);
+        const unsigned lvoff = cidx * 16u;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            unsigned v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = (u < SHIFT_LIST && u < t_slot) ? newkeys[wave][pr][u][lane] : 0u;  // uniform bound
+            sort16_desc(v);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int di = 2 * pr + h;
+                if (d0 + di < NDOY) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        unsigned w[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const unsigned a = v[8 * jj + 2 * i], b = v[8 * jj + 2 * i + 1];
+                            w[i] = h == 0 ? ((a & 0xFFFFu) | (b << 16)) : ((a >> 16) | (b & 0xFFFF0000u));
+                        }
+                        const int li = __builtin_amdgcn_readfirstlane((di * tails.nper + t_list) * 2 + jj);
+                        if (active) tl_out_store(rl, lvoff, (unsigned)li * (unsigned)C * 16u, w);
+                    }
+                }
+            }
+        }
+        ++t_list;
+        t_slot = 0;
+    };
+
+    // mid: once per wave and year, behind the wave's last read of the stage -- the barrier that frees the stage, next year's rows
+    // on their way into it, the record of the year after asked for
+    auto mid = [&](const int4& cA) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (cA.x & LR_STAGE_NEXT) dma_rows(cA.z, cA.w);
+        nA = lr_next[0];
+        nB = lr_next[1];
+        lr_next += LSTRIDE;
+    };
+    // Rows r0 .. r0 + 2 NPAIR - 1 (r0 = first timestep - H) come in TWO halves through the same registers (the 24 rows of a
+    // year at once are 12 registers this kernel does not have): pairs [0, NH0) then [NH0, NPAIR).  how: 0 the stage, 1 memory,
+    // 2 memory with rows outside the series clamped (the caller replaces the affected sums by NaN).
+    constexpr int NH0 = (NPAIR + 1) / 2, NH1 = NPAIR - NH0;
+    static_assert(NH0 >= 2, "the second chain starts in the first half");
+    v2f xh[NH0];
+    v2f accA = splat2(0.f), accB = splat2(0.f);
+    float xc0 = 0.f, xc1 = 0.f, xc2 = 0.f, xc3 = 0.f;
+    auto load_half = [&](auto Pc, int how, int ts) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value, M0 = P ? NH0 : 0, MN = P ? NH1 : NH0;
+        if (how == 0) {
+            const float* st = &stage[(4 * wave) * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < MN; ++m) {
+                xh[m].x = st[(2 * (M0 + m)) * 64];
+                xh[m].y = st[(2 * (M0 + m) + 1) * 64];
+            }
+        } else if (how == 1) {
+            const rsrc_t rx = make_rsrc(x + (size_t)(ts - H) * (size_t)C);
+#pragma unroll
+            for (int m = 0; m < MN; ++m) {
+                xh[m].x = ldb_f32(rx, voff, (2 * (M0 + m)) * rowb);
+                xh[m].y = ldb_f32(rx, voff, (2 * (M0 + m) + 1) * rowb);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MN; ++m) {
+                int ra = ts - H + 2 * (M0 + m), rb = ra + 1;
+                ra = ra < 0 ? 0 : (ra > T - 1 ? T - 1 : ra);
+                rb = rb < 0 ? 0 : (rb > T - 1 ? T - 1 : rb);
+                xh[m].x = ldb_f32(make_rsrc(x + (size_t)ra * (size_t)C), voff, 0);
+                xh[m].y = ldb_f32(make_rsrc(x + (size_t)rb * (size_t)C), voff, 0);
+            }
+        }
+    };
+    // sequential sums of rows i .. i+S-1 for the four dayofyears i = 0..3 (two chains per instruction, skewed by one row) and
+    // the centre rows H .. H+3, the part that the pairs of half P feed
+    auto half = [&](auto Pc) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value, M0 = P ? NH0 : 0, M1 = P ? NPAIR : NH0;
+        if (P == 0) accA = (v2f){xh[0].x, -0.0f};
+#pragma unroll
+        for (int s = 1; s <= S - 1; ++s)
+            if ((s >> 1) >= M0 && (s >> 1) < M1) accA = (s & 1) ? pk_add_bc_hi(accA, xh[(s >> 1) - M0]) : pk_add_bc_lo(accA, xh[(s >> 1) - M0]);
+        if ((S >> 1) >= M0 && (S >> 1) < M1) accA.y += xh[(S >> 1) - M0].y;
+        if (1 >= M0 && 1 < M1) accB = (v2f){xh[1 - M0].x, -0.0f};
+#pragma unroll
+        for (int s = 3; s <= S + 1; ++s)
+            if ((s >> 1) >= M0 && (s >> 1) < M1) accB = (s & 1) ? pk_add_bc_hi(accB, xh[(s >> 1) - M0]) : pk_add_bc_lo(accB, xh[(s >> 1) - M0]);
+        if (((S + 2) >> 1) >= M0 && ((S + 2) >> 1) < M1) accB.y += xh[((S + 2) >> 1) - M0].y;
+#define MAREX_XC(i, dst) \
+    if (((H + i) >> 1) >= M0 && ((H + i) >> 1) < M1) dst = ((H + i) & 1) ? xh[((H + i) >> 1) - M0].y : xh[((H + i) >> 1) - M0].x;
+        MAREX_XC(0, xc0) MAREX_XC(1, xc1) MAREX_XC(2, xc2) MAREX_XC(3, xc3)
+#undef MAREX_XC
+    };
+    // mid() runs between the second half's loads and its sums
+    auto smooth = [&](const int4& cA, v2f& smA, v2f& smB, v2f& xcA, v2f& xcB, int how, int ts) __attribute__((always_inline)) {
+        load_half(std::integral_constant<int, 0>{}, how, ts);
+        half(std::integral_constant<int, 0>{});
+        load_half(std::integral_constant<int, 1>{}, how, ts);
+        mid(cA);
+        half(std::integral_constant<int, 1>{});
+        smA = div_const2(accA, Sf, yS);
+        smB = div_const2(accB, Sf, yS);
+        xcA = (v2f){xc0, xc1};
+        xcB = (v2f){xc2, xc3};
+    };
+    constexpr bool recip_exact = (W & 1) || (W & (W - 1)) == 0;
+    auto digit2 = [&](v2f a, int& k0, int& k1) __attribute__((always_inline)) {  // np.digitize - 1 on the arange table (see k_shift_fast)
+        const v2f f = __builtin_elementwise_fma(a, splat2(inv_width), splat2(c0));
+        v2f t;
+        t.x = __builtin_amdgcn_fmed3f(__builtin_floorf(f.x), 0.0f, nbm1f);
+        t.y = __builtin_amdgcn_fmed3f(__builtin_floorf(f.y), 0.0f, nbm1f);
+        const v2f phi = t * splat2(e_delta);
+        const v2f ehi = splat2(e_first) + phi;
+        k0 = (int)t.x + (a.x >= ehi.x ? 1 : 0);
+        k1 = (int)t.y + (a.y >= ehi.y ? 1 : 0);
+    };
+    // climatology of the W entries from J on + the anomaly; nanmean where the plain mean is NaN while the centre value is a number
+    auto anomaly = [&](auto Jc, v2f xcA, v2f xcB, v2f& aA, v2f& aB) __attribute__((always_inline)) {
+        constexpr int J = decltype(Jc)::value;
+        v2f sA = splat2(0.f), sB = splat2(0.f);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            sA = sA + hA[J + j];
+            sB = sB + hB[J + j];
+        }
+        v2f climA, climB;
+        if (recip_exact) {
+            climA = div_const2(sA, Wf, yW);
+            climB = div_const2(sB, Wf, yW);
+        } else {
+            climA = (v2f){sA.x / Wf, sA.y / Wf};
+            climB = (v2f){sB.x / Wf, sB.y / Wf};
+        }
+        const bool slow = (!(climA.x == climA.x) && xcA.x == xcA.x) || (!(climA.y == climA.y) && xcA.y == xcA.y) ||
+                          (!(climB.x == climB.x) && xcB.x == xcB.x) || (!(climB.y == climB.y) && xcB.y == xcB.y);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) != 0, 0)) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            int n[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const float v[4] = {hA[J + j].x, hA[J + j].y, hB[J + j].x, hB[J + j].y};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (v[i] == v[i]) {
+                        acc[i] += v[i];
+                        ++n[i];
+                    }
+            }
+            if (!(climA.x == climA.x)) climA.x = acc[0] / (float)n[0];
+            if (!(climA.y == climA.y)) climA.y = acc[1] / (float)n[1];
+            if (!(climB.x == climB.x)) climB.x = acc[2] / (float)n[2];
+            if (!(climB.y == climB.y)) climB.y = acc[3] / (float)n[3];
+        }
+        aA = xcA - climA;
+        aB = xcB - climB;
+    };
+
+    // ---- a REGULAR year (all 4 dayofyears present, staged, no edge, one bucket position): no look at the calendar
+    auto lean_year = [&](auto Jc, const int4& cA, const int4& cB) __attribute__((always_inline)) {
+        constexpr int J = decltype(Jc)::value;
+        v2f smA, smB, xcA, xcB;
+        smooth(cA, smA, smB, xcA, xcB, 0, 0);
+        n_invalid += (finite_f(xcA.x) ? 0 : 1) + (finite_f(xcA.y) ? 0 : 1) + (finite_f(xcB.x) ? 0 : 1) + (finite_f(xcB.y) ? 0 : 1);
+        if (cA.x & LR_OUT) {
+            v2f aA, aB;
+            anomaly(Jc, xcA, xcB, aA, aB);
+            int k0, k1, k2, k3;
+            digit2(aA, k0, k1);
+            digit2(aB, k2, k3);
+            const unsigned pos = (unsigned)cB.z, kb = 128u + pos;  // ((k + 1) << 7) | pos = (k << 7) + (128 + pos)
+            const bool v0 = aA.x < e_last, v1 = aA.y < e_last, v2 = aB.x < e_last, v3 = aB.y < e_last;  // countable: a number below the last edge
+            const unsigned q0 = v0 ? ((unsigned)k0 << TAIL_POS_BITS) + kb : 0u, q1 = v1 ? ((unsigned)k1 << TAIL_POS_BITS) + kb : 0u;
+            const unsigned q2 = v2 ? ((unsigned)k2 << TAIL_POS_BITS) + kb : 0u, q3 = v3 ? ((unsigned)k3 << TAIL_POS_BITS) + kb : 0u;
+            newkeys[wave][0][t_slot][lane] = q0 | (q1 << 16);
+            newkeys[wave][1][t_slot][lane] = q2 | (q3 << 16);
+            t_cntA += (v0 ? 1u : 0u) + (v1 ? 0x10000u : 0u);
+            t_cntB += (v2 ? 1u : 0u) + (v3 ? 0x10000u : 0u);
+            const float mx = fmaxf(fmaxf(aA.x, aA.y), fmaxf(aB.x, aB.y));  // maxNum skips NaN
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx >= e_last) != 0, 0)) {  // values beyond the table: positions into the aux word
+                unsigned s0 = t_ovfA & 0xFFFFu, s1 = t_ovfA >> 16, s2 = t_ovfB & 0xFFFFu, s3 = t_ovfB >> 16;
+                if (aA.x >= e_last) s0 = tail_ovf_add(s0, pos);
+                if (aA.y >= e_last) s1 = tail_ovf_add(s1, pos);
+                if (aB.x >= e_last) s2 = tail_ovf_add(s2, pos);
+                if (aB.y >= e_last) s3 = tail_ovf_add(s3, pos);
+                t_ovfA = s0 | (s1 << 16);
+                t_ovfB = s2 | (s3 << 16);
+            }
+            ++t_slot;
+            const unsigned long long ooff = ((unsigned long long)(unsigned)cB.y << 32) | (unsigned)cB.x;
+            const rsrc_t ro = make_rsrc(reinterpret_cast<char*>(out) + ooff);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next year's rows have landed; the stores below stay in flight
+            if (active) {  // lanes beyond C hold other cells' rows (DMA): they store nothing
+                stb_f32(ro, voff, 0, aA.x);
+                stb_f32(ro, voff, rowb, aA.y);
+                stb_f32(ro, voff, 2 * rowb, aB.x);
+                stb_f32(ro, voff, 3 * rowb, aB.y);
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        hA[J + W] = smA;  // year y joins the history
+        hB[J + W] = smB;
+    };
+
+    // ---- any other year (k_shift_fast's body): first days of the series, the leap-day chunk, trailing partial years, waves
+    // that only help staging
+    auto general_year = [&](auto Jc, int y, const int4& cA) __attribute__((always_inline)) {
+        constexpr int J = decltype(Jc)::value;
+        v2f smA = splat2(qnan), smB = splat2(qnan);
+        int4 pA = make_int4(-1, -1, 0, 0), pB = make_int4(0, 0, 0, 0);
+        if (mine) {
+            pA = fplan[((size_t)y * 92 + chunk) * 2];
+            pB = fplan[((size_t)y * 92 + chunk) * 2 + 1];
+        }
+        const int nd = pA.z & 0xFF;
+        if (mine && nd > 0) {
+            const int tb = cA.y, r0 = pA.x - H;
+            const bool edge = r0 < 0 || r0 + 2 * NPAIR > T;
+            const bool staged = tb >= H && tb - H + NROWS <= T && pA.x == tb + 4 * wave;
+            v2f xcA, xcB;
+            smooth(cA, smA, smB, xcA, xcB, staged ? 0 : (edge ? 2 : 1), pA.x);
+            if (edge) {  // windows that leave the series: NaN
+                const int t0 = pA.x;
+                smA.x = (t0 - H >= 0 && t0 + H < T) ? smA.x : qnan;
+                smA.y = (t0 + 1 - H >= 0 && t0 + 1 + H < T) ? smA.y : qnan;
+                smB.x = (t0 + 2 - H >= 0 && t0 + 2 + H < T) ? smB.x : qnan;
+                smB.y = (t0 + 3 - H >= 0 && t0 + 3 + H < T) ? smB.y : qnan;
+            }
+            const bool has1 = nd > 1, has2 = nd > 2, has3 = nd > 3;
+            n_invalid += finite_f(xcA.x) ? 0 : 1;
+            if (has1) n_invalid += finite_f(xcA.y) ? 0 : 1; else smA.y = qnan;
+            if (has2) n_invalid += finite_f(xcB.x) ? 0 : 1; else smB.x = qnan;
+            if (has3) n_invalid += finite_f(xcB.y) ? 0 : 1; else smB.y = qnan;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (pA.y >= 0) {  // output rows
+                v2f aA, aB;
+                anomaly(Jc, xcA, xcB, aA, aB);
+                const rsrc_t ro = make_rsrc(out + (size_t)pA.y * (size_t)C);
+                if (active) {
+                    stb_f32(ro, voff, 0, aA.x);
+                    if (has1) stb_f32(ro, voff, rowb, aA.y);
+                    if (has2) stb_f32(ro, voff, 2 * rowb, aB.x);
+                    if (has3) stb_f32(ro, voff, 3 * rowb, aB.y);
+                }
+                int k0, k1, k2, k3;
+                digit2(aA, k0, k1);
+                digit2(aB, k2, k3);
+                const float l1 = has1 ? e_last : -__builtin_inff(), l2 = has2 ? e_last : -__builtin_inff(),
+                            l3 = has3 ? e_last : -__builtin_inff();  // uniform
+                const bool v0 = aA.x < e_last, v1 = aA.y < l1, v2 = aB.x < l2, v3 = aB.y < l3;
+                const int ds0 = tails.doy_start[d0], ds1 = tails.doy_start[d0 + 1 < NDOY ? d0 + 1 : NDOY - 1];
+                const int ds2 = tails.doy_start[d0 + 2 < NDOY ? d0 + 2 : NDOY - 1], ds3 = tails.doy_start[d0 + 3 < NDOY ? d0 + 3 : NDOY - 1];
+                const unsigned p0 = (unsigned)(pA.w - ds0), p1 = (unsigned)(pB.x - ds1), p2 = (unsigned)(pB.y - ds2), p3 = (unsigned)(pB.z - ds3);
+                const unsigned q0 = v0 ? ((unsigned)k0 << TAIL_POS_BITS) + 128u + p0 : 0u, q1 = v1 ? ((unsigned)k1 << TAIL_POS_BITS) + 128u + p1 : 0u;
+                const unsigned q2 = v2 ? ((unsigned)k2 << TAIL_POS_BITS) + 128u + p2 : 0u, q3 = v3 ? ((unsigned)k3 << TAIL_POS_BITS) + 128u + p3 : 0u;
+                newkeys[wave][0][t_slot][lane] = q0 | (q1 << 16);
+                newkeys[wave][1][t_slot][lane] = q2 | (q3 << 16);
+                t_cntA += (v0 ? 1u : 0u) + (v1 ? 0x10000u : 0u);
+                t_cntB += (v2 ? 1u : 0u) + (v3 ? 0x10000u : 0u);
+                const float mx = fmaxf(fmaxf(aA.x, has1 ? aA.y : aA.x), fmaxf(has2 ? aB.x : aA.x, has3 ? aB.y : aA.x));
+                if (__builtin_amdgcn_ballot_w64(mx >= e_last) != 0) {
+                    unsigned s0 = t_ovfA & 0xFFFFu, s1 = t_ovfA >> 16, s2 = t_ovfB & 0xFFFFu, s3 = t_ovfB >> 16;
+                    if (aA.x >= e_last) s0 = tail_ovf_add(s0, p0);
+                    if (has1 && aA.y >= e_last) s1 = tail_ovf_add(s1, p1);
+                    if (has2 && aB.x >= e_last) s2 = tail_ovf_add(s2, p2);
+                    if (has3 && aB.y >= e_last) s3 = tail_ovf_add(s3, p3);
+                    t_ovfA = s0 | (s1 << 16);
+                    t_ovfB = s2 | (s3 << 16);
+                }
+                ++t_slot;
+            }
+        } else {
+            mid(cA);  // nothing to compute: the barrier, the staging and the record prefetch all the same
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        hA[J + W] = smA;
+        hB[J + W] = smB;
+    };
+
+    for (int y = 0; y < n_cal; y += 2) {
+        {
+            const int4 cA = nA, cB = nB;
+            if (mine && (cA.x & LR_REG)) {
+                lean_year(std::integral_constant<int, 0>{}, cA, cB);
+                ++n_lean;
+            } else {
+                general_year(std::integral_constant<int, 0>{}, y, cA);
+                n_gen += mine ? 1 : 0;
+            }
+            asm volatile("s_barrier" ::: "memory");  // every wave's DMA has landed: the stage holds next year's rows
+            if (t_slot == SHIFT_LIST) tails_flush();
+        }
+        if (y + 1 < n_cal) {
+            const int4 cA = nA, cB = nB;
+            if (mine && (cA.x & LR_REG)) {
+                lean_year(std::integral_constant<int, 1>{}, cA, cB);
+                ++n_lean;
+            } else {
+                general_year(std::integral_constant<int, 1>{}, y + 1, cA);
+                n_gen += mine ? 1 : 0;
+            }
+            asm volatile("s_barrier" ::: "memory");
+            if (t_slot == SHIFT_LIST) tails_flush();
+        }
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            hA[j] = hA[j + 2];
+            hB[j] = hB[j + 2];
+        }
+    }
+    if (mine) {
+        if (t_slot > 0) tails_flush();
+        while (t_list < tails.nper) tails_flush();
+        if (active) {
+            const unsigned cn[4] = {t_cntA & 0xFFFFu, t_cntA >> 16, t_cntB & 0xFFFFu, t_cntB >> 16};
+            const unsigned ov[4] = {t_ovfA & 0xFFFFu, t_ovfA >> 16, t_ovfB & 0xFFFFu, t_ovfB >> 16};
+#pragma unroll
+            for (int di = 0; di < 4; ++di)
+                if (d0 + di < NDOY) tails.aux[(size_t)(d0 + di) * (size_t)C + c] = tail_aux_word(cn[di], ov[di]);
+        }
+    }
+    if (invalid_count && active && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
+    if (tails.dbg && lane == 0) {
+        atomicAdd(&tails.dbg[6], (unsigned long long)n_lean);
+        atomicAdd(&tails.dbg[7], (unsigned long long)n_gen);
+    }
+}
+
+static bool lean_instance(int W, int S) { return S == 21 && (W == 15 || W == 5); }
 
 struct ShiftArgs {
     const float* x;
@@ -868,6 +1465,8 @@ struct ShiftArgs {
     int32_t* invalid_count;
     const int* skip;
     TailOut tails;
+    bool lean = false;  // k_shift_lean takes the tails configuration
+    const int4* lplan = nullptr;  // its lean records
 };
 
 template <int D, int SCAP, bool SEXACT, int WCAP, bool RREG>
@@ -889,14 +1488,28 @@ static int launch_shifting(marex_ctx* ctx, const ShiftArgs& a) {
 template <int W, int S = 21>
 static void launch_shift_fast(marex_ctx* ctx, const ShiftArgs& a) {
     const int ncg = (int)((a.C + 63) / 64);
-    if (a.tails.lists)
-        hipLaunchKernelGGL((k_shift_fast<W, true, S>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C,
-                           a.fplan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask,
-                           a.invalid_count, ncg, 23, a.tails);
-    else
-        hipLaunchKernelGGL((k_shift_fast<W, false, S>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C,
-                           a.fplan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask,
-                           a.invalid_count, ncg, 23, a.tails);
+#define MAREX_SF_ARGS dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C, a.fplan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask, a.invalid_count, ncg, 23, a.tails
+    if (a.tails.lists && a.lean) {
+        if constexpr (S == 21 && (W == 15 || W == 5))
+            hipLaunchKernelGGL((k_shift_lean<W, S>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (int)a.T, (int)a.C, a.fplan,
+                               a.lplan, a.n_cal, a.skip, a.edges, a.nb, a.out, a.mask, a.invalid_count, ncg, 23, a.tails);
+    } else if (a.tails.lists) {
+        // LDS-DMA staging + L2 prefetch (option SHIFT_DMA=1; measured round 3 on a 100-yr band: 12.17 ms against 11.84 ms with
+        // the rows staged through VGPRs -- the kernel is bound by instruction issue, not by the latency of its loads -- so it
+        // is off by default and instantiated for the two benchmark shapes only): whole 16-byte segments of a row are either
+        // inside the field or beyond it (C a multiple of 4), and the prefetch offset of 365 rows fits the 32-bit buffer offset
+        constexpr int RPW = (S + 15 + 3) / 4;
+        constexpr bool has_dma = S == 21 && (W == 15 || W == 5);
+        const bool dma = has_dma && ctx_opt(ctx, "SHIFT_DMA", 0) != 0 && a.C >= 4 && a.C % 4 == 0 &&
+                         (unsigned long long)(365 + 4 * RPW + 4) * (unsigned long long)a.C * 4ull < 0xFFFFFFFFull;
+        if (dma)
+            hipLaunchKernelGGL((k_shift_fast<W, true, S, has_dma>), MAREX_SF_ARGS);
+        else
+            hipLaunchKernelGGL((k_shift_fast<W, true, S, false>), MAREX_SF_ARGS);
+    } else {
+        hipLaunchKernelGGL((k_shift_fast<W, false, S, false>), MAREX_SF_ARGS);
+    }
+#undef MAREX_SF_ARGS
 }
 
 template <int D, int WCAP, bool RREG>
@@ -944,8 +1557,24 @@ static int shifting_impl(marex_ctx* ctx, const char* who, const float* x, int64_
     }
     LaunchTimer lt(ctx, MAREX_K_SHIFTING);  // one timed region: classify + fast kernel + general kernel
     if (fast_cfg) {
+        // the lean kernel stages its rows by LDS-DMA: whole 16-byte segments of a row inside the field or beyond it (C % 4 == 0)
+        const bool lean = tails.lists && lean_instance(W, S) && ctx_opt(ctx, "SHIFT_LEAN", 1) != 0 && C >= 4 && C % 4 == 0 &&
+                          T < (1ll << 31) - 64 && (unsigned long long)(4 * ((S + 18) / 4) + 4) * (unsigned long long)C * 4ull < 0xFFFFFFFFull;
+        if (lean && ctx->shift_lplan_years < (size_t)n_cal_years) {
+            if (ctx->shift_lplan) {
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                (void)hipFree(ctx->shift_lplan);
+                ctx->shift_lplan = nullptr;
+                ctx->shift_lplan_years = 0;
+            }
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->shift_lplan, ((size_t)n_cal_years + 2) * 92 * 8 * sizeof(int)));
+            ctx->shift_lplan_years = (size_t)n_cal_years;
+        }
         hipLaunchKernelGGL(k_shift_classify, dim3(1), dim3(1024), 0, ctx->stream, a.year_plan, n_cal_years, edges, nb,
-                           (bins || tails.lists) ? 1 : 0, 1, ctx->shift_info, reinterpret_cast<int4*>(ctx->shift_plan));
+                           (bins || tails.lists) ? 1 : 0, 1, ctx->shift_info, reinterpret_cast<int4*>(ctx->shift_plan), (long)T, (long)C,
+                           lean ? S : 0, lean ? reinterpret_cast<int4*>(ctx->shift_lplan) : nullptr, tails.doy_start);
+        a.lplan = reinterpret_cast<const int4*>(ctx->shift_lplan);
+        a.lean = lean;
         a.skip = ctx->shift_info;
         a.fplan = reinterpret_cast<const int4*>(ctx->shift_plan);
         if (S == 11 || S == 15) {
@@ -992,12 +1621,12 @@ extern "C" int marex_shifting_baseline_f32(marex_ctx* ctx, const float* x, int64
 // defined in marex_tails.hip: extraction restricted to the dayofyear chunks a flag table does NOT mark (skip == NULL: all)
 int marex_tail_extract_impl(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
                             const int32_t* doy_rows, int max_bucket, const float* edges, int nb, int list_rows, void* lists,
-                            uint16_t* aux, const int* skip_chunks);
+                            uint32_t* aux, const int* skip_chunks);
 
 extern "C" int marex_shifting_baseline_tails_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* year_plan,
                                                  int n_cal_years, int W, int S, const float* edges, int nb, int64_t T_out,
                                                  float* out, uint8_t* mask, int32_t* invalid_count, const int32_t* doy_start,
-                                                 const int32_t* doy_rows, int max_bucket, void* lists, uint16_t* aux) {
+                                                 const int32_t* doy_rows, int max_bucket, void* lists, uint32_t* aux) {
     if (!ctx) return -1;
     if (!doy_start || !doy_rows || !lists || !aux) return fail(ctx, -1, "marex_shifting_baseline_tails_f32: null pointer");
     if (nb > TAIL_MAX_NB || max_bucket < 1 || max_bucket > 6 * SHIFT_LIST || C > (1 << 24))

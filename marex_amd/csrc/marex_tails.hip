@@ -72,7 +72,7 @@ __global__ void k_row_offsets(const int* __restrict__ doy_rows, long T_out, long
 __global__ void __launch_bounds__(256)
 k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ doy_start, const long long* __restrict__ row_off,
                const float* __restrict__ edges, int nb, int NPER, int list_rows, uint4* __restrict__ lists,
-               unsigned short* __restrict__ aux, const int* __restrict__ skip_chunks) {
+               unsigned* __restrict__ aux, const int* __restrict__ skip_chunks) {
     extern __shared__ float e[];  // [nb + 1]
     const int nch = list_rows <= 16 ? 2 : 4;  // 16-byte chunks per list
     const int tid = threadIdx.x;
@@ -112,7 +112,7 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
         const int d0 = 2 * pp, d1 = d0 + 1;
         const int s0 = doy_start[d0], n0 = doy_start[d0 + 1] - s0;
         const int s1 = doy_start[d1], n1 = doy_start[d1 + 1] - s1;
-        unsigned cnt = 0, ovf = 0;  // packed: low half dayofyear d0, high half d1
+        unsigned cnt = 0, ovf = 0;  // packed: low half dayofyear d0, high half d1 (ovf: tail_ovf_add states)
         for (int p = 0; p < NPER; ++p) {
             unsigned half[2][16];
             const int l0 = p * list_rows, l1 = l0 + list_rows;  // rows of this list
@@ -144,8 +144,21 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
                     const bool oa = ba < nb, ob = bb < nb;
                     const unsigned ka = oa ? tail_key(ba, pos) : 0u, kb = ob ? tail_key(bb, pos) : 0u;
                     cnt += (oa ? 1u : 0u) + (ob ? 0x10000u : 0u);
-                    ovf |= (va[u] >= e_last ? 1u : 0u) | (vb[u] >= e_last ? 0x10000u : 0u);  // false for NaN
                     half[hb][u] = ka | (kb << 16);
+                }
+                {  // samples beyond the table (false for NaN): next to never -- one test per batch, their positions in a re-walk
+                    float mx = -__builtin_inff();
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) mx = fmaxf(mx, fmaxf(va[u], vb[u]));  // maxNum skips NaN
+                    if (__builtin_amdgcn_ballot_w64(mx >= e_last) != 0) {
+                        unsigned sa = ovf & 0xFFFFu, sb = ovf >> 16;
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            if (va[u] >= e_last) sa = tail_ovf_add(sa, (unsigned)(r + u));
+                            if (vb[u] >= e_last) sb = tail_ovf_add(sb, (unsigned)(r + u));
+                        }
+                        ovf = sa | (sb << 16);
+                    }
                 }
                 sort16_desc(half[hb]);
             }
@@ -184,8 +197,8 @@ k_tail_extract(const float* __restrict__ anom, long C, const int* __restrict__ d
             }
         }
         if (active) {
-            aux[(size_t)d0 * C + c] = (unsigned short)((cnt & 0xFFFFu) | ((ovf & 0xFFFFu) ? 0x8000u : 0u));
-            aux[(size_t)d1 * C + c] = (unsigned short)((cnt >> 16) | ((ovf >> 16) ? 0x8000u : 0u));
+            aux[(size_t)d0 * C + c] = tail_aux_word(cnt & 0xFFFFu, ovf & 0xFFFFu);
+            aux[(size_t)d1 * C + c] = tail_aux_word(cnt >> 16, ovf >> 16);
         }
     }
     };
@@ -209,7 +222,7 @@ extern "C" int marex_tail_lists(int max_bucket, int list_rows) {
 
 int marex_tail_extract_impl(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
                             const int32_t* doy_rows, int max_bucket, const float* edges, int nb, int list_rows, void* lists,
-                            uint16_t* aux, const int* skip_chunks) {
+                            uint32_t* aux, const int* skip_chunks) {
     if (!ctx) return -1;
     if (!anom || !doy_start || !doy_rows || !edges || !lists || !aux || T_out <= 0 || C <= 0)
         return fail(ctx, -1, "marex_tail_extract_f32: null pointer or empty shape");
@@ -245,7 +258,7 @@ int marex_tail_extract_impl(marex_ctx* ctx, const float* anom, int64_t T_out, in
 
 extern "C" int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t T_out, int64_t C, const int32_t* doy_start,
                                       const int32_t* doy_rows, int max_bucket, const float* edges, int nb, int list_rows,
-                                      void* lists, uint16_t* aux) {
+                                      void* lists, uint32_t* aux) {
     return marex_tail_extract_impl(ctx, anom, T_out, C, doy_start, doy_rows, max_bucket, edges, nb, list_rows, lists, aux, nullptr);
 }
 
@@ -285,7 +298,7 @@ struct TailBucket {
 
 template <int P, int TC, int NT, int NPERT, int TR_ = NT / TC>
 __global__ void __launch_bounds__(NT, NT == 256 ? 4 : (NT == 512 ? 2 : 1))
-k_thr_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ aux, int NPER, int nch, const float* __restrict__ anom,
+k_thr_tails(const uint4* __restrict__ lists, const unsigned* __restrict__ aux, int NPER, int nch, const float* __restrict__ anom,
             long C, int ny, int nx, int row0, int row1, int tiles_x, int Dd, const float* __restrict__ centres, int nb, double q,
             int wd, float lower_bound, float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats,
             unsigned long long* __restrict__ dbg) {
@@ -791,7 +804,7 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ 
 template <int NSC>  // NSC > 0: the ring has exactly NSC slots and a day's probes count from a REGISTER copy of it (one LDS read of
                     // the ring per day instead of one per probe: the probes of a day form a dependent chain, LDS latency included)
 __global__ void __launch_bounds__(64)
-k_thr_cells(const uint4* __restrict__ lists, const unsigned short* __restrict__ aux, int NPER, int nch, const float* __restrict__ anom,
+k_thr_cells(const uint4* __restrict__ lists, const unsigned* __restrict__ aux, int NPER, int nch, const float* __restrict__ anom,
             long C, long c0, long c1, int nblk, const float* __restrict__ centres, int nb, double q, int wd, float lower_bound,
             float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats, unsigned long long* __restrict__ dbg) {
     extern __shared__ uint4 ring[];  // [wd * NPER rounded up to a multiple of 4][64]; the padding stays zero (no keys)
@@ -978,7 +991,7 @@ k_thr_cells(const uint4* __restrict__ lists, const unsigned short* __restrict__ 
     }
 }
 
-extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, int list_rows,
+extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lists, const uint32_t* aux, int list_rows,
                                                  const float* anom, int64_t T_out, int64_t C, int ny, int nx, int max_bucket,
                                                  const float* centres,
                                                  int nb, double q, int wd, int ws, float lower_bound, float upper_bound, int row0,
@@ -1109,7 +1122,7 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
 #endif
 template <int NPERT>  // lists handled per group (their first chunks are in flight together)
 __global__ void __launch_bounds__(256, MASK_WAVES)
-k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__ aux, int NPER_all, int nch, const float* __restrict__ anom,
+k_mask_tails(const uint4* __restrict__ lists, const unsigned* __restrict__ aux, int NPER_all, int nch, const float* __restrict__ anom,
              const float* __restrict__ edges, int nb, const float* __restrict__ thr, const int* __restrict__ doy_start,
              const int* __restrict__ doy_rows, const long long* __restrict__ row_off, const long long* __restrict__ row_off_anom,
              long C, long c0, long c1, unsigned char* __restrict__ out, unsigned long long* __restrict__ n_true,
@@ -1126,8 +1139,9 @@ k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__
             if (nd == 0) continue;
             const float4 th4 = *reinterpret_cast<const float4*>(thr + (size_t)d * C + c);
             const float tv[4] = {th4.x, th4.y, th4.z, th4.w};
-            const uint2 ax = *reinterpret_cast<const uint2*>(aux + (size_t)d * C + c);
-            const unsigned av[4] = {ax.x & 0xFFFFu, ax.x >> 16, ax.y & 0xFFFFu, ax.y >> 16};
+            const uint4 ax = *reinterpret_cast<const uint4*>(aux + (size_t)d * C + c);
+            const unsigned av[4] = {ax.x, ax.y, ax.z, ax.w};
+            unsigned beyond = 0;  // some cell of the lane has samples beyond the table and a threshold that is a number
             unsigned bits[4][4];
             unsigned lim_ge[4];  // keys > lim_ge: bin >= the threshold's bin
             int kt[4];
@@ -1137,7 +1151,8 @@ k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__
                 bits[i][0] = bits[i][1] = bits[i][2] = bits[i][3] = 0u;
                 const bool isnum = tv[i] == tv[i];
                 kt[i] = isnum ? digitize_bin(tv[i], edges, nb, inv_width) : nb;  // NaN threshold: nothing is extreme
-                slow = slow || (isnum && (av[i] & 0x8000u));                        // values beyond the table: look at them
+                slow = slow || (isnum && (av[i] & TAIL_AUX_MANY));                  // more than two values beyond the table: look at them
+                beyond |= (isnum && (av[i] & TAIL_AUX_BEYOND)) ? 1u : 0u;
                 walk[i] = isnum && (av[i] & 0x3FFu) > 0 && kt[i] < nb;
                 const unsigned lim = ((unsigned)(kt[i] + 1) << TAIL_POS_BITS) - 1u;
                 lim_ge[i] = lim | (lim << 16);
@@ -1248,6 +1263,21 @@ k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__
                 }
             }
             }  // list groups
+            // samples beyond the table have no key but are extremes of every finite threshold: their positions come with aux
+            if (__builtin_amdgcn_ballot_w64(beyond != 0u && !slow) != 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (!slow && tv[i] == tv[i] && (av[i] & TAIL_AUX_BEYOND)) {
+                        const int p1 = (int)((av[i] >> 16) & 0x7Fu), p2 = (int)((av[i] >> 23) & 0x7Fu);
+                        const bool two = (av[i] & TAIL_AUX_SECOND) != 0u;
+#pragma unroll
+                        for (int wi = 0; wi < 4; ++wi) {
+                            if ((p1 >> 5) == wi) bits[i][wi] |= 1u << (p1 & 31);
+                            if (two && (p2 >> 5) == wi) bits[i][wi] |= 1u << (p2 & 31);
+                        }
+                    }
+                }
+            }
             if (slow) {
                 ++n_slow;
                 for (int r = 0; r < nd; ++r) {
@@ -1298,7 +1328,7 @@ k_mask_tails(const uint4* __restrict__ lists, const unsigned short* __restrict__
     }
 }
 
-extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, const uint16_t* aux, int list_rows, int max_bucket,
+extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, const uint32_t* aux, int list_rows, int max_bucket,
                                            const float* anom,
                                            const float* edges, int nb, const float* thr_doy_major, const int32_t* doy_start,
                                            const int32_t* doy_rows, int64_t T_out, int64_t C, int64_t c0, int64_t c1,
@@ -1311,7 +1341,7 @@ extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, co
     if (!tails_geometry(max_bucket, list_rows, NPER, nch))
         return fail(ctx, -4, "marex_mask_ge_doy_tails_f32: buckets must hold 1..%d rows, lists 8..32 rows", TAIL_MAX_BUCKET);
     const bool vec = (C % 4 == 0) && (c0 % 4 == 0) && (c1 % 4 == 0) && (((uintptr_t)anom | (uintptr_t)thr_doy_major) % 16 == 0) &&
-                     ((uintptr_t)extreme % 4 == 0) && ((uintptr_t)aux % 8 == 0) && nb < 0x7fff;
+                     ((uintptr_t)extreme % 4 == 0) && ((uintptr_t)aux % 16 == 0) && nb < 0x7fff;
     if (!vec)  // shapes the 4-cell kernel does not cover: the plain compare on the anomalies
         return marex_mask_ge_doy_f32(ctx, anom, thr_doy_major, doy_start, doy_rows, T_out, C, c0, c1, extreme, n_true);
     HIP_TRY(ctx, hipSetDevice(ctx->device));

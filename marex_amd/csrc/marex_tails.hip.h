@@ -16,8 +16,12 @@
 //                                       ceil(max_bucket / 32) lists of <= 32 keys, each sorted descending (list p holds
 //                                       rows 32 p .. 32 p + 31 of the bucket).  Chunk-major: one 16-byte load per lane,
 //                                       contiguous across consecutive cells; consumers rarely go past chunk 0.
-//   aux[d][c] (uint16)                  bits 0..9: number of keys of the bucket (= the samples the reference counts);
-//                                       bit 15: the bucket holds a non-NaN value >= edges[nb] (only the mask cares)
+//   aux[d][c] (uint32)                  bits 0..9: number of keys of the bucket (= the samples the reference counts);
+//                                       bit 15: the bucket holds a non-NaN value >= edges[nb] ("beyond the table": no key, the
+//                                       histogram drops it, but it IS an extreme of any finite threshold -- only the mask
+//                                       cares); bits 16..22 / 23..29: position of the first / second such sample of the
+//                                       bucket, bit 30: the second exists, bit 31: there are more than two (only then does
+//                                       the mask kernel have to look at the bucket's values)
 //
 // The sorting network works on PACKED PAIRS: one 32-bit register holds the keys of two independent buckets (two
 // neighbouring dayofyears of one cell), v_pk_max_u16 / v_pk_min_u16 order both at once.
@@ -96,3 +100,19 @@ MAREX_HD void sort16_desc(unsigned (&v)[16]) {
 }
 
 MAREX_HD unsigned tail_key(int bin, int pos) { return ((unsigned)(bin + 1) << TAIL_POS_BITS) | (unsigned)pos; }
+
+// Samples beyond the table, per bucket, while the producer walks it in time order: a 16-bit state [n:2][pos1:7][pos2:7]
+// (n = 3: more than two), turned into the upper half of the aux word at the end.
+#define TAIL_AUX_COUNT 0x3FFu
+#define TAIL_AUX_BEYOND 0x8000u     // at least one sample beyond the table
+#define TAIL_AUX_SECOND 0x40000000u // pos2 is valid
+#define TAIL_AUX_MANY 0x80000000u   // more than two: look at the values
+MAREX_HD unsigned tail_ovf_add(unsigned st, unsigned pos) {
+    const unsigned n = st & 3u;
+    return n == 0u ? (1u | (pos << 2)) : (n == 1u ? (2u | (st & 0x1FCu) | (pos << 9)) : (st | 3u));
+}
+MAREX_HD unsigned tail_aux_word(unsigned cnt, unsigned st) {
+    const unsigned n = st & 3u;
+    return cnt | (n ? TAIL_AUX_BEYOND : 0u) | (((st >> 2) & 0x7Fu) << 16) | (((st >> 9) & 0x7Fu) << 23) |
+           (n >= 2u ? TAIL_AUX_SECOND : 0u) | (n == 3u ? TAIL_AUX_MANY : 0u);
+}

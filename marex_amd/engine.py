@@ -257,7 +257,7 @@ class HotPath:
         nper = (nd + list_rows - 1) // list_rows
         nch = 2 if list_rows <= 16 else 4
         lists = self._buf(wsp, "tails", (N_DOY, nper, nch, Cn, 8), torch.int16, self.device)
-        aux = self._buf(wsp, "tails_aux", (N_DOY, Cn), torch.int16, self.device)
+        aux = self._buf(wsp, "tails_aux", (N_DOY, Cn), torch.int32, self.device)
         return lists, aux
 
     def tail_extract(self, anom: torch.Tensor, dcal: DeviceCalendar, bins: BinTable, wsp: Optional[dict] = None,

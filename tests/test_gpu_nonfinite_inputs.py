@@ -39,7 +39,7 @@ def test_digitize_and_tails_on_special_values(hot):
         assert np.array_equal(got, exp.astype(np.uint16))
         tl = hot.tail_extract(ad, dcal, bt)
         hot.sync()
-        aux = tl["aux"].cpu().numpy().view(np.uint16)
+        aux = tl["aux"].cpu().numpy().view(np.uint32)
         valid = (exp < bt.nb)
         for d in (0, 59, 200, 365):
             rows = slice(cal.doy_start[d], cal.doy_start[d + 1])

@@ -115,13 +115,14 @@ def test_two_stage_fallback_keeps_the_raw_validation_outputs_with_a_workspace(ho
     """detrend_fixed_baseline as two stages (DETREND_FUSED=0, or more than five terms) with a SHARED workspace: the second
     stage's mask / count buffers are its own, so the returned mask and invalid counts are still those of the raw field."""
     tm, x = _field("2001-01-01", 7 * 365 + 2, 4, 11)
-    x[100:130, 5] = np.nan   # an ocean cell with a gap
-    x[40, 7] = np.inf
+    ocean = np.flatnonzero(np.isfinite(x[0]))
+    x[100:130, ocean[2]] = np.nan   # an ocean cell with a gap
+    x[40, ocean[4]] = np.inf
     cal = calendar.build_calendar(tm)
     dcal = hot.upload_calendar(cal)
     xd = torch.from_numpy(x).to(hot.device)
     exp_mask, exp_inv = np.isfinite(x[0]), (~np.isfinite(x)).sum(axis=0)
-    assert exp_inv[5] == 30 and exp_inv[7] == 1
+    assert exp_inv[ocean[2]] == 30 and exp_inv[ocean[4]] == 1
     for orders, opts in (([1, 2], dict(DETREND_FUSED=0)), ([1, 2, 3, 4, 5], {})):
         model, pmodel = calendar.detrend_model(calendar.decimal_year(tm), orders, False)
         wsp = {}

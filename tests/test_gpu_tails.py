@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 
 def tails_reference(anom, cal, edges):
     """NumPy statement of the tails of ``anom`` [T_out, C]: per bucket the sorted (descending) keys of ALL its countable
-    samples, keys[366, max_bucket, C] (0 = none), and aux[366, C]."""
+    samples, keys[366, max_bucket, C] (0 = none), and aux[366, C] (uint32: count, "beyond the table" flag, the positions
+    of the first two such samples of the bucket, "second exists", "more than two" -- csrc/marex_tails.hip.h)."""
     nb = edges.size - 1
     T_out, C = anom.shape
     nmax = int(np.diff(cal.doy_start).max())
@@ -27,7 +28,7 @@ def tails_reference(anom, cal, edges):
         bins = np.digitize(anom, edges) - 1
         over = (anom >= edges[-1]) & ~np.isnan(anom)
     keys = np.zeros((366, nmax, C), dtype=np.uint16)
-    aux = np.zeros((366, C), dtype=np.uint16)
+    aux = np.zeros((366, C), dtype=np.uint32)
     for d in range(366):
         rows = cal.doy_rows[cal.doy_start[d]:cal.doy_start[d + 1]]
         if rows.size == 0:
@@ -36,7 +37,13 @@ def tails_reference(anom, cal, edges):
         valid = b < nb
         k = np.where(valid, ((b + 1) << 7) | np.arange(rows.size)[:, None], 0).astype(np.uint16)
         keys[d, :rows.size] = -np.sort(-k.astype(np.int32), axis=0)
-        aux[d] = valid.sum(axis=0).astype(np.uint16) | np.where(over[rows].any(axis=0), 0x8000, 0).astype(np.uint16)
+        ov = over[rows]                                   # [n, C] beyond the table, in time order
+        n_ov = ov.sum(axis=0)
+        order = np.argsort(~ov, axis=0, kind="stable")    # positions of the True entries first, ascending
+        p1 = np.where(n_ov >= 1, order[0], 0).astype(np.uint32)
+        p2 = np.where(n_ov >= 2, order[1] if rows.size > 1 else 0, 0).astype(np.uint32)
+        aux[d] = (valid.sum(axis=0).astype(np.uint32) | np.where(n_ov >= 1, 0x8000, 0).astype(np.uint32) | (p1 << 16) | (p2 << 23)
+                  | np.where(n_ov >= 2, 0x40000000, 0).astype(np.uint32) | np.where(n_ov >= 3, 0x80000000, 0).astype(np.uint32))
     return keys, aux
 
 
@@ -48,7 +55,7 @@ def device_tails_to_keys(tl, C):
     lists_sorted = bool((np.diff(per_list.astype(np.int32), axis=2) <= 0).all())
     allk = per_list.reshape(366, nper * nch * 8, C)
     allk = -np.sort(-allk.astype(np.int32), axis=1)
-    return allk.astype(np.uint16), tl["aux"].cpu().numpy().view(np.uint16), lists_sorted
+    return allk.astype(np.uint16), tl["aux"].cpu().numpy().view(np.uint32), lists_sorted
 
 
 def make_anomalies(T_years=12, C=300, seed=3, start="2000-01-01", sigma=0.8):
@@ -162,7 +169,7 @@ def test_constant_and_extreme_data(hot):
     anom[:, 120:130] = np.float32(4.985)       # the last countable bins: above the upper warning bound
     bt = binning.hobday_bins()
     c = _thr_case(hot, anom, cal, bt, 95.0, 11, 5, 10, 16)
-    assert c[4] > 0, c            # buckets with values beyond the table: the mask looked at the anomalies
+    assert c[4] > 0, c            # buckets with more than two values beyond the table: the mask looked at the anomalies
     _thr_case(hot, anom, cal, bt, 95.0, 11, 1, 10, 16)
 
 
@@ -213,3 +220,23 @@ def test_per_cell_threshold_kernel_without_spatial_pooling(hot, years, pct, wd, 
         _thr_case(hot, anom[:, :330].copy(), cal, bt, pct, wd, 1, 11, 30, rows=(2, 9), list_rows=list_rows,
                   opts={"THR_CELLS": 2, "THR_CELLS_BLOCKS": 5})
         _thr_case(hot, anom[:, :330].copy(), cal, bt, pct, wd, 1, 11, 30, rows=(2, 9), list_rows=list_rows)  # the default choice
+
+
+@pytest.mark.parametrize("per_bucket", [1, 2, 3])
+def test_outliers_beyond_the_table_stay_on_the_list_path(hot, per_bucket):
+    """Samples at or beyond ``max_anomaly`` have no key (the histogram drops them) but are extremes of every finite
+    threshold.  One or two per bucket travel in the aux word and the mask places them without reading the anomalies (no slow
+    group: the mask kernel's time does not depend on outliers); three or more fall back to the compare on the values.  Same
+    bits as the oracle either way, for both list geometries and with / without pooling."""
+    tm, cal, anom, rng = make_anomalies(20, 12 * 16, seed=21)
+    anom[:, 3] = np.nan
+    for d in range(366):  # `per_bucket` samples of every bucket of every third cell go beyond the table (+inf among them)
+        rows = cal.doy_rows[cal.doy_start[d]:cal.doy_start[d + 1]]
+        for c in range(0, anom.shape[1], 3):
+            pick = rng.choice(rows, size=min(per_bucket, rows.size), replace=False)
+            anom[pick, c] = np.float32(5.0 + rng.random()) if (c // 3) % 2 == 0 else np.float32(np.inf)
+    anom[:, 3] = np.nan
+    bt = binning.hobday_bins()
+    for list_rows, ws, ny, nx in ((15, 5, 12, 16), (32, 5, 12, 16), (15, None, 0, 12 * 16)):
+        c = _thr_case(hot, anom, cal, bt, 95.0, 11, ws, ny, nx, list_rows=list_rows)
+        assert (c[4] == 0) == (per_bucket <= 2), (per_bucket, c)
