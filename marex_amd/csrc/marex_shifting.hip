@@ -1109,11 +1109,12 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
     int4 nA = lr_next[0], nB = lr_next[1];  // year 0
     lr_next += LSTRIDE;
 
-    // history of dayofyears (0,1) and (2,3) as register lines; the year loop is unrolled by two: the first year of a pair reads
-    // entries [0, W) and appends at [W], the second reads [1, W] and appends at [W + 1], then the line moves down by two
-    v2f hA[W + 2], hB[W + 2];
+    // history of dayofyears (0,1) and (2,3) as register lines; the year loop is unrolled by U: year J of a group reads entries
+    // [J, J + W) and appends at [J + W], then the line moves down by U -- 4 W register moves per U years
+    constexpr int U = W >= 13 ? 3 : 4;  // W = 15: 122 VGPRs with three years per group, spills with four
+    v2f hA[W + U], hB[W + U];
 #pragma unroll
-    for (int j = 0; j < W + 2; ++j) hA[j] = hB[j] = splat2(qnan);
+    for (int j = 0; j < W + U; ++j) hA[j] = hB[j] = splat2(qnan);
     int n_invalid = 0;
     unsigned t_cntA = 0, t_cntB = 0, t_ovfA = 0, t_ovfB = 0;
     int t_slot = 0, t_list = 0;
@@ -1398,37 +1399,32 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
         hB[J + W] = smB;
     };
 
-    for (int y = 0; y < n_cal; y += 2) {
-        {
-            const int4 cA = nA, cB = nB;
-            if (mine && (cA.x & LR_REG)) {
-                lean_year(std::integral_constant<int, 0>{}, cA, cB);
-                ++n_lean;
-            } else {
-                general_year(std::integral_constant<int, 0>{}, y, cA);
-                n_gen += mine ? 1 : 0;
-            }
-            asm volatile("s_barrier" ::: "memory");  // every wave's DMA has landed: the stage holds next year's rows
-            if (t_slot == SHIFT_LIST) tails_flush();
-        }
-        if (y + 1 < n_cal) {
-            const int4 cA = nA, cB = nB;
-            if (mine && (cA.x & LR_REG)) {
-                lean_year(std::integral_constant<int, 1>{}, cA, cB);
-                ++n_lean;
-            } else {
-                general_year(std::integral_constant<int, 1>{}, y + 1, cA);
-                n_gen += mine ? 1 : 0;
-            }
-            asm volatile("s_barrier" ::: "memory");
-            if (t_slot == SHIFT_LIST) tails_flush();
-        }
+    // (a lambda around the year makes hipcc keep a closure -- and with it a history line -- in scratch memory: a macro it is)
+#define MAREX_LEAN_YEAR(J, yy)                                                                                  \
+    {                                                                                                           \
+        const int4 cA = nA, cB = nB;                                                                            \
+        if (mine && (cA.x & LR_REG)) {                                                                          \
+            lean_year(std::integral_constant<int, J>{}, cA, cB);                                                \
+            ++n_lean;                                                                                           \
+        } else {                                                                                                \
+            general_year(std::integral_constant<int, J>{}, yy, cA);                                             \
+            n_gen += mine ? 1 : 0;                                                                              \
+        }                                                                                                       \
+        asm volatile("s_barrier" ::: "memory"); /* every wave's DMA has landed: the stage holds next year's rows */ \
+        if (t_slot == SHIFT_LIST) tails_flush();                                                                \
+    }
+    for (int y = 0; y < n_cal; y += U) {
+        MAREX_LEAN_YEAR(0, y)
+        if constexpr (U > 1) if (y + 1 < n_cal) MAREX_LEAN_YEAR(1, y + 1)
+        if constexpr (U > 2) if (y + 2 < n_cal) MAREX_LEAN_YEAR(2, y + 2)
+        if constexpr (U > 3) if (y + 3 < n_cal) MAREX_LEAN_YEAR(3, y + 3)
 #pragma unroll
         for (int j = 0; j < W; ++j) {
-            hA[j] = hA[j + 2];
-            hB[j] = hB[j + 2];
+            hA[j] = hA[j + U];
+            hB[j] = hB[j + U];
         }
     }
+#undef MAREX_LEAN_YEAR
     if (mine) {
         if (t_slot > 0) tails_flush();
         while (t_list < tails.nper) tails_flush();
