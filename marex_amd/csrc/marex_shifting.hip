@@ -1111,7 +1111,7 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
 
     // history of dayofyears (0,1) and (2,3) as register lines; the year loop is unrolled by U: year J of a group reads entries
     // [J, J + W) and appends at [J + W], then the line moves down by U -- 4 W register moves per U years
-    constexpr int U = W >= 13 ? 3 : 4;  // W = 15: 122 VGPRs with three years per group, spills with four
+    constexpr int U = W >= 13 ? 3 : 2;  // W = 15: 122 VGPRs with three years per group, spills with four
     v2f hA[W + U], hB[W + U];
 #pragma unroll
     for (int j = 0; j < W + U; ++j) hA[j] = hB[j] = splat2(qnan);
@@ -1437,10 +1437,12 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
         }
     }
     if (invalid_count && active && n_invalid) atomicAdd(&invalid_count[c], n_invalid);
+#ifdef MAREX_LEAN_COUNTERS  // diagnostic builds only: two atomics per wave on two addresses cost 4 ms on a 10-yr field (750 000 waves)
     if (tails.dbg && lane == 0) {
         atomicAdd(&tails.dbg[6], (unsigned long long)n_lean);
         atomicAdd(&tails.dbg[7], (unsigned long long)n_gen);
     }
+#endif
 }
 
 static bool lean_instance(int W, int S) { return S == 21 && (W == 15 || W == 5); }
