@@ -1151,7 +1151,9 @@ k_mask_tails(const uint4* __restrict__ lists, const unsigned* __restrict__ aux, 
                 bits[i][0] = bits[i][1] = bits[i][2] = bits[i][3] = 0u;
                 const bool isnum = tv[i] == tv[i];
                 kt[i] = isnum ? digitize_bin(tv[i], edges, nb, inv_width) : nb;  // NaN threshold: nothing is extreme
-                slow = slow || (isnum && (av[i] & TAIL_AUX_MANY));                  // more than two values beyond the table: look at them
+                // values beyond the table are extremes of every threshold INSIDE the table (any threshold the histogram quantile
+                // produces); more than two of them, or a threshold beyond the table itself: look at the values
+                slow = slow || (isnum && (av[i] & TAIL_AUX_BEYOND) && ((av[i] & TAIL_AUX_MANY) || kt[i] >= nb));
                 beyond |= (isnum && (av[i] & TAIL_AUX_BEYOND)) ? 1u : 0u;
                 walk[i] = isnum && (av[i] & 0x3FFu) > 0 && kt[i] < nb;
                 const unsigned lim = ((unsigned)(kt[i] + 1) << TAIL_POS_BITS) - 1u;
