@@ -283,6 +283,48 @@ extern "C" int marex_tail_extract_f32(marex_ctx* ctx, const float* anom, int64_t
 // so the inner pieces are written for instruction count: packed 16-bit prefix sums, counted key prefixes instead of
 // per-key branches, buffer addressing with wave-uniform bases.
 // ------------------------------------------------------------------------------------------------
+
+// The first n keys of a chunk (n <= 8, all at or above the band's first bin) added to (SGN > 0) or removed from the lane's packed
+// level column: level = min(bin + 1 - B0, BW + 1), two uint16 levels per dword.  Lanes drop out of the loop for good as the key
+// index passes their n, so the execution mask only ever shrinks: v_cmpx + s_cbranch_execz per key, the mask saved and restored
+// once -- hipcc's form of the same loop (compare, branch on the ballot, s_and_saveexec, branch, restore, per key) spent 5 scalar
+// and branch instructions per key where this spends one, in the loop that is most of the threshold kernel's column update.
+#define MAREX_BUMP_KEY(u, w, ext)                                                                                   \
+    "v_cmpx_lt_u32_e32 vcc, " #u ", %[n]\n\ts_cbranch_execz 1f\n\t" ext "\n\t"                                      \
+    "v_subrev_u32_e32 %[t], %[b0], %[t]\n\tv_min_i32_e32 %[t], %[hi], %[t]\n\tv_and_b32_e32 %[a], -2, %[t]\n\t"       \
+    "v_and_b32_e32 %[t], 1, %[t]\n\tv_lshl_add_u32 %[a], %[a], 1, %[col]\n\t"
+#define MAREX_BUMP_LO(w) "v_bfe_u32 %[t], %[" #w "], 7, 9"
+#define MAREX_BUMP_HI(w) "v_lshrrev_b32_e32 %[t], 23, %[" #w "]"
+template <int SGN>
+__device__ __forceinline__ void tl_bump_chunk(const uint4& ch, int n, int B0, int BWp1, unsigned col_lds) {
+    unsigned t, a;
+    unsigned long long sv;
+    const int mul = SGN > 0 ? 65535 : -65535;
+#define MAREX_BUMP_ADD(one) "v_mad_i32_i24 %[t], %[t], %[mul], " one "\n\tds_add_u32 %[a], %[t]\n\t"
+#define MAREX_BUMP_ALL(one)                                                                                          \
+    "s_mov_b64 %[sv], exec\n\t"                                                                                      \
+    MAREX_BUMP_KEY(0, x, MAREX_BUMP_LO(x)) MAREX_BUMP_ADD(one) MAREX_BUMP_KEY(1, x, MAREX_BUMP_HI(x)) MAREX_BUMP_ADD(one)   \
+    MAREX_BUMP_KEY(2, y, MAREX_BUMP_LO(y)) MAREX_BUMP_ADD(one) MAREX_BUMP_KEY(3, y, MAREX_BUMP_HI(y)) MAREX_BUMP_ADD(one)   \
+    MAREX_BUMP_KEY(4, z, MAREX_BUMP_LO(z)) MAREX_BUMP_ADD(one) MAREX_BUMP_KEY(5, z, MAREX_BUMP_HI(z)) MAREX_BUMP_ADD(one)   \
+    MAREX_BUMP_KEY(6, w, MAREX_BUMP_LO(w)) MAREX_BUMP_ADD(one) MAREX_BUMP_KEY(7, w, MAREX_BUMP_HI(w)) MAREX_BUMP_ADD(one)   \
+    "1:\n\ts_mov_b64 exec, %[sv]"
+    if (SGN > 0)
+        asm volatile(MAREX_BUMP_ALL("1")
+                     : [t] "=&v"(t), [a] "=&v"(a), [sv] "=&s"(sv)
+                     : [n] "v"(n), [x] "v"(ch.x), [y] "v"(ch.y), [z] "v"(ch.z), [w] "v"(ch.w), [b0] "s"(B0), [hi] "s"(BWp1), [col] "v"(col_lds), [mul] "s"(mul)
+                     : "vcc", "memory");
+    else
+        asm volatile(MAREX_BUMP_ALL("-1")
+                     : [t] "=&v"(t), [a] "=&v"(a), [sv] "=&s"(sv)
+                     : [n] "v"(n), [x] "v"(ch.x), [y] "v"(ch.y), [z] "v"(ch.z), [w] "v"(ch.w), [b0] "s"(B0), [hi] "s"(BWp1), [col] "v"(col_lds), [mul] "s"(mul)
+                     : "vcc", "memory");
+#undef MAREX_BUMP_ALL
+#undef MAREX_BUMP_ADD
+}
+#undef MAREX_BUMP_KEY
+#undef MAREX_BUMP_LO
+#undef MAREX_BUMP_HI
+
 #define TT_LS 34       // dwords per lane column (68 uint16 levels; stride 34 keeps 8-byte alignment, conflict-free b64)
 #define TT_BW 64       // bins per band
 #define TT_MARGIN 6    // re-centre when the day's quantile bins come this close to a band edge
@@ -383,6 +425,7 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned* __restrict__ aux, i
     };
     int mytot = 0;  // valid samples in this lane's window
     // the first n keys of a chunk (n <= 8, all inside the band) into the column
+    constexpr bool ctx_asm_bump = true;  // (the C++ loop below is what it replaces; kept for reference builds)
     auto bump_chunk = [&](const uint4& ch, int n, int sgn, int nfix) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -408,7 +451,8 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned* __restrict__ aux, i
         auto one_list = [&](const uint4& ch, int p) {
             const int n = cnt > 0 ? tl_count_above(ch, lim_rep) : 0;
             n_in += n;
-            bump_chunk(ch, n, sgn, NPERT >= 3 ? 2 : 1);
+            if (ctx_asm_bump) { if (sgn > 0) tl_bump_chunk<1>(ch, n, B0, BW + 1, col_lds); else tl_bump_chunk<-1>(ch, n, B0, BW + 1, col_lds); }
+            else bump_chunk(ch, n, sgn, NPERT >= 3 ? 2 : 1);
             bool full = n == 8;
 #pragma unroll
             for (int jj = 1; jj < 4; ++jj) {
@@ -416,7 +460,8 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned* __restrict__ aux, i
                 const uint4 cj = tl_load_chunk(r, voff, (unsigned)(nch * p + jj) * chunk_row);
                 const int nj = full ? tl_count_above(cj, lim_rep) : 0;
                 n_in += nj;
-                bump_chunk(cj, nj, sgn, 0);
+                if (ctx_asm_bump) { if (sgn > 0) tl_bump_chunk<1>(cj, nj, B0, BW + 1, col_lds); else tl_bump_chunk<-1>(cj, nj, B0, BW + 1, col_lds); }
+                else bump_chunk(cj, nj, sgn, 0);
                 full = nj == 8;
             }
         };
