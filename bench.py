@@ -298,8 +298,18 @@ def main():
         ny_total = wl["ny"] * world
     shard = shards[0]
 
-    nstream = args.streams if args.streams > 0 else (1 if (len(shards) == 1 or one_gpu) else 2)
+    # default: three engines when their workspaces fit beside the resident input (measured on the 100-yr field: 143.6 ms with one
+    # stream, 133.5 with two, 131.5 with three), else two; one for a single band and for the one-GPU rehearsal of several ranks
+    nstream = args.streams if args.streams > 0 else (1 if (len(shards) == 1 or one_gpu) else 3)
     nstream = max(1, min(nstream, len(shards)))
+    if args.streams <= 0 and nstream == 3:
+        cells = max(sh.cells_in for sh in shards)
+        # an engine's workspace: anomalies (4 B) and extremes (1 B) per output step, thresholds twice, the sorted key lists
+        per_engine = cells * (5 * T + 12 * 366) + cells * 2 * 366 * 16 * (T // 365 // 15 + 1)
+        resident = sum(sh.cells_in for sh in shards) * 4 * T
+        free = torch.cuda.mem_get_info(local_rank)[0]
+        if resident + 3 * per_engine * 1.1 > free:
+            nstream = 2
     eset = EngineSet(local_rank, nstream) if nstream > 1 else None
     hot = eset.engines[0] if eset else HotPath(local_rank)
     for e in (eset.engines if eset else [hot]):
@@ -398,7 +408,9 @@ def main():
         dom = max(kern, key=lambda k: kern[k][0])
         # HBM bytes of the dominant kernel from the committed PMC passes of this same command (profiles/)
         traffic = None
-        knames = {"shifting": "k_shift_fast", "tails": "k_tail_extract", "transpose": "k_transpose", "detrend": "k_detrend", "fixed": "k_fixed_baseline",
+        lean = (path == "tails" and detrend is None and step_kw["S"] == 21 and step_kw["W"] in (5, 15) and shard.cells_in % 4 == 0
+                and os.environ.get("MAREX_SHIFT_LEAN", "1") != "0")  # engine.shifting_baseline_tails -> k_shift_lean (csrc/marex_shifting.hip)
+        knames = {"shifting": "k_shift_lean" if lean else "k_shift_fast", "tails": "k_tail_extract", "transpose": "k_transpose", "detrend": "k_detrend", "fixed": "k_fixed_baseline",
                   "thresholds": "k_thr_tails" if path == "tails" else "k_thr_band",
                   "mask": "k_mask_tails" if path == "tails" else "k_mask_ge"}
         kname = knames[dom]
