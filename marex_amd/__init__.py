@@ -19,10 +19,11 @@ from .exceptions import (
     ProcessingError,
     create_data_validation_error,
 )
+from .dask_adapter import preprocess_data_lazy
 from .xr_compat import DataArray, Dataset
 
 __all__ = [
-    "preprocess_data", "compute_normalised_anomaly", "identify_extremes", "rolling_climatology",
+    "preprocess_data", "preprocess_data_lazy", "compute_normalised_anomaly", "identify_extremes", "rolling_climatology",
     "smoothed_rolling_climatology", "MarExError", "DataValidationError", "ConfigurationError",
     "ProcessingError", "DependencyError", "create_data_validation_error", "DataArray", "Dataset",
 ]

@@ -1,0 +1,219 @@
+"""Lazy, block-wise ``preprocess_data`` for Dask-backed inputs.
+
+The reference lays its hot path out as ``{time: -1, space: chunked}`` (marEx/detect.py:2617-2620) and hands the result back
+chunked ``{time: dask_chunks["time"], space: -1}`` (detect.py:785-792).  This module does the same with the MI355X engine
+behind every spatial chunk:
+
+* the field is cut into spatial blocks that keep the whole time axis -- latitude bands with ``window_spatial_hobday // 2``
+  overlap rows per interior side on grids (longitude stays whole: the pooling wraps there), cell ranges on meshes;
+* every block is ONE lazy task (``dask.delayed``) that brings its rows to the host, runs
+  :func:`marex_amd.preprocess_data` on them on the device and returns the owned part of every output variable;
+* the Dataset variables are ``dask.array.from_delayed`` views of those tasks, concatenated along the cut axis and rechunked
+  like the reference's output.  Nothing is computed until the caller computes / persists / writes the Dataset, and a
+  scheduler with several workers (``devices=[...]``: one GPU per worker slot, round-robin) processes blocks concurrently.
+
+Differences from the eager call, by construction: ``_validate_data_values`` (detect.py:205-279) speaks about the whole field,
+so its verdict is reduced over the blocks by :func:`validation_summary` (a lazy scalar task the caller may compute first:
+``check_valid=True`` does so before returning, as the reference validates eagerly, detect.py:583); the threshold-range
+warnings are emitted per block.
+
+Needs ``dask`` (and works on ``xarray.DataArray`` as well as on the stand-in ``marex_amd.DataArray`` wrapping a Dask array).
+Neither package exists in the build image: the task function :func:`run_block` -- everything except the graph wiring -- is
+plain NumPy in / NumPy out and is tested on the GPU without Dask (tests/test_gpu_dask_adapter.py); the wiring is tested behind
+``pytest.importorskip("dask")``.
+"""
+
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .detect import _infer_dims_coords, _raise_if_invalid, _validate_extreme_options, preprocess_data
+from .dist import Shard, plan_shards
+from .exceptions import DependencyError, create_data_validation_error
+from .xr_compat import DataArray, Dataset, coord_values
+
+#: output variables of one block and where their spatial axes sit: "t" = (time', *space), "s" = (*space), "sd" = (*space, dayofyear),
+#: "ds" = (dayofyear, *space)
+_LAYOUT = {"dat_anomaly": "t", "extreme_events": "t", "mask": "s", "dat_stn": "t", "extreme_events_stn": "t", "STD": "sd"}
+
+
+def plan_spatial_blocks(ny: int, nx: int, halo: int, block_rows: Optional[int] = None, block_cells: Optional[int] = None) -> List[Shard]:
+    """Latitude bands of about ``block_rows`` rows (``ny > 0``) or cell ranges of about ``block_cells`` cells (``ny == 0``)."""
+    if ny > 0:
+        rows = int(block_rows) if block_rows else ny
+        return plan_shards(ny, nx, max(1, -(-ny // max(rows, 1))), halo)
+    cells = int(block_cells) if block_cells else nx
+    return plan_shards(0, nx, max(1, -(-nx // max(cells, 1))), 0)
+
+
+def run_block(x_block: np.ndarray, time: np.ndarray, shard: Shard, gridded: bool, dims: Sequence[str], coords: Dict[str, np.ndarray],
+              kwargs: dict, device: int = 0) -> Dict[str, object]:
+    """One spatial block on the device.  ``x_block``: ``[T, rows_in, nx]`` / ``[T, cells_in]`` (overlap rows included), returns
+    the OWNED part of every output variable as NumPy arrays plus the block's validation counts (``"_validation"``) and the
+    kept time axis (``"_time"``)."""
+    x_block = np.asarray(x_block)
+    da = DataArray(x_block, dims=tuple(dims), coords={**coords, dims[0]: time})
+    if gridded:
+        r0, r1 = shard.own0 - shard.in0, shard.own1 - shard.in0
+    else:
+        r0, r1 = 0, shard.cells_own  # meshes carry no overlap
+    ds = preprocess_data(da, device=device, _validation="return", _own_rows=(r0, r1), **kwargs)
+    out: Dict[str, object] = {"_validation": dict(ds.attrs["_validation"]), "_attrs": {k: v for k, v in ds.attrs.items() if k != "_validation"}}
+    for name in ds.data_vars:
+        v = ds[name]
+        a = np.asarray(v.values)
+        vd = tuple(v.dims)
+        axis = vd.index(dims[1])  # first spatial dim (lat, or the cell axis)
+        sl = [slice(None)] * a.ndim
+        sl[axis] = slice(r0, r1)
+        out[name] = np.ascontiguousarray(a[tuple(sl)])
+        out[f"_dims:{name}"] = vd
+    out["_time"] = np.asarray(coord_values(ds["dat_anomaly"], dims[0]))
+    return out
+
+
+def _reduce_validation(parts: Sequence[Dict[str, int]]) -> Dict[str, int]:
+    tot = {"n_ocean": 0, "invalid_total": 0, "invalid_cells": 0, "max_invalid": 0}
+    for p in parts:
+        for k in ("n_ocean", "invalid_total", "invalid_cells"):
+            tot[k] += int(p[k])
+        tot["max_invalid"] = max(tot["max_invalid"], int(p["max_invalid"]))
+    return tot
+
+
+class _ShapeOnly:
+    """What ``_raise_if_invalid`` reads of a field: its shape."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+def preprocess_data_lazy(da, *, block_rows: Optional[int] = None, block_cells: Optional[int] = None, devices: Optional[List[int]] = None,
+                         check_valid: bool = False, dask_chunks: Optional[Dict[str, int]] = None, dimensions=None, coordinates=None,
+                         **kwargs):
+    """``preprocess_data`` as a lazy Dask graph over spatial blocks with ``time: -1`` (module docstring).  ``da`` must be
+    Dask-backed (the reference's own requirement, detect.py:558-568); keyword arguments are those of
+    :func:`marex_amd.preprocess_data`.  Returns a Dataset whose variables are Dask arrays, chunked
+    ``{time: dask_chunks["time"] (default 25), space: -1}``; ``ds.attrs["validation"]`` is the lazy whole-field verdict
+    (:func:`validation_summary`), raised as the reference's ``DataValidationError`` when computed through
+    :func:`raise_if_invalid` -- ``check_valid=True`` does that before returning."""
+    try:
+        import dask
+        import dask.array as dsa
+        from dask.base import is_dask_collection
+    except Exception as exc:  # pragma: no cover - dask is absent in the build image
+        raise DependencyError("preprocess_data_lazy needs dask", details=str(exc)) from exc
+
+    dimensions, coordinates = _infer_dims_coords(da, dimensions, coordinates)
+    data = da.data
+    if not is_dask_collection(data):  # detect.py:558-568
+        raise create_data_validation_error(
+            "Input DataArray must be Dask-backed",
+            details="Preprocessing requires chunked data for efficient computation",
+            suggestions=["Convert to Dask array: da = da.chunk({'time': 30})", "Load with chunking: xr.open_dataset('file.nc', chunks={'time': 30})"],
+            data_info={"data_type": type(data).__name__, "shape": tuple(da.shape)},
+        )
+    gridded = "y" in dimensions
+    tdim = dimensions["time"]
+    sdims = [dimensions["y"], dimensions["x"]] if gridded else [dimensions["x"]]
+    order = [tdim, *sdims]
+    if tuple(da.dims) != tuple(order):
+        data = data.transpose([list(da.dims).index(d) for d in order])
+    time = np.asarray(coord_values(da, coordinates["time"]))
+    T = data.shape[0]
+    ny, nx = (data.shape[1], data.shape[2]) if gridded else (0, data.shape[1])
+    kw = dict(kwargs)
+    ws_eff = _validate_extreme_options(
+        gridded, kw.get("method_extreme", "hobday_extreme"), kw.get("threshold_percentile", 95), kw.get("window_days_hobday", 11),
+        kw.get("window_spatial_hobday"), kw.get("method_percentile", "approximate"), kw.get("precision", 0.01), kw.get("max_anomaly", 5.0))
+    halo = (int(ws_eff) // 2) if (ws_eff and kw.get("method_extreme", "hobday_extreme") == "hobday_extreme"
+                                 and kw.get("method_percentile", "approximate") == "approximate") else 0
+    shards = plan_spatial_blocks(ny, nx, halo, block_rows, block_cells)
+    data = data.rechunk({0: -1})  # time: -1 (detect.py:2617)
+    dev_list = [int(d) for d in devices] if devices else [0]
+    kw.update(dimensions=dict(dimensions), coordinates=dict(coordinates))
+    # coordinates that live on the spatial dims (lat / lon axes of a grid, per-cell lat / lon of a mesh): a block gets its slice
+    cut = sdims[0]
+    space_coords = []  # (name, dims, values)
+    for name in da.coords:
+        cd = tuple(da.coords[name].dims)
+        if name != coordinates["time"] and cd and all(d in sdims for d in cd):
+            space_coords.append((name, cd, np.asarray(coord_values(da, name))))
+
+    def block_coords(sh: Shard):
+        out = {}
+        for name, cd, val in space_coords:
+            if cut in cd:
+                sl = [slice(None)] * val.ndim
+                sl[cd.index(cut)] = slice(sh.in0, sh.in1)
+                val = val[tuple(sl)]
+            out[name] = val if cd == (name,) else (cd, val)
+        return out
+
+    tasks = []
+    for i, sh in enumerate(shards):
+        xb = data[:, sh.in0:sh.in1]
+        tasks.append(dask.delayed(run_block, pure=True)(xb, time, sh, gridded, order, block_coords(sh), kw, dev_list[i % len(dev_list)]))
+
+    # output shapes need the kept time axis and the threshold layout: both follow from the options, without computing anything
+    from . import calendar as _cal
+
+    W = kw.get("window_year_baseline", 15)
+    shifting = kw.get("method_anomaly", "shifting_baseline") == "shifting_baseline"
+    cal = _cal.build_calendar(time, window_year_baseline=int(W) if shifting else None)
+    T_out, time_out = cal.T_out, time[cal.kept]
+    me, mp = kw.get("method_extreme", "hobday_extreme"), kw.get("method_percentile", "approximate")
+    thr_layout = "s" if me == "global_extreme" else ("ds" if mp == "exact" else "sd")
+    thr_dtype = np.float64 if me == "global_extreme" else np.float32
+    want_stn = bool(kw.get("std_normalise", False)) and kw.get("method_anomaly", "shifting_baseline") == "detrend_harmonic"
+    names = {"dat_anomaly": np.float32, "mask": np.bool_, "extreme_events": np.bool_, "thresholds": thr_dtype}
+    layout = dict(_LAYOUT, thresholds=thr_layout, thresholds_stn=thr_layout)
+    if want_stn:
+        names.update({"dat_stn": np.float32, "STD": np.float32, "extreme_events_stn": np.bool_, "thresholds_stn": thr_dtype})
+
+    def shape_of(kind, sh: Shard):
+        sp = (sh.own1 - sh.own0, nx) if gridded else (sh.cells_own,)
+        return {"t": (T_out, *sp), "s": sp, "sd": (*sp, 366), "ds": (366, *sp)}[kind]
+
+    doy = np.arange(1, 367)
+    ds = Dataset()
+    for name, dt in names.items():
+        kind = layout[name]
+        axis = {"t": 1, "s": 0, "sd": 0, "ds": 1}[kind]
+        parts = [dsa.from_delayed(dask.delayed(lambda r, n=name: r[n])(t), shape=shape_of(kind, sh), dtype=dt) for t, sh in zip(tasks, shards)]
+        arr = dsa.concatenate(parts, axis=axis) if len(parts) > 1 else parts[0]
+        vdims = {"t": (tdim, *sdims), "s": tuple(sdims), "sd": (*sdims, "dayofyear"), "ds": ("dayofyear", *sdims)}[kind]
+        # final rechunk (detect.py:785-792): space whole, time (and dayofyear) in chunks of dask_chunks["time"]
+        tch = int((dask_chunks or {}).get(tdim, (dask_chunks or {}).get("time", 25)))
+        chunks = {i: (tch if d in (tdim, "dayofyear") else -1) for i, d in enumerate(vdims)}
+        arr = arr.rechunk(chunks)
+        vcoords = {}
+        if tdim in vdims:
+            vcoords[tdim] = time_out
+        if "dayofyear" in vdims:
+            vcoords["dayofyear"] = doy
+        for cname, cd, val in space_coords:
+            if all(d in vdims for d in cd):
+                vcoords[cname] = val if cd == (cname,) else (cd, val)
+        ds[name] = DataArray(arr, dims=vdims, coords=vcoords)
+    verdict = dask.delayed(_reduce_validation)([dask.delayed(lambda r: r["_validation"])(t) for t in tasks])
+    ds.attrs["validation"] = verdict
+    ds.attrs["_field_shape"] = (int(T), int(ny * nx if gridded else nx))
+    ds.attrs.update({"method_anomaly": kw.get("method_anomaly", "shifting_baseline"), "method_extreme": me,
+                     "threshold_percentile": kw.get("threshold_percentile", 95)})
+    if check_valid:
+        raise_if_invalid(ds)
+    return ds
+
+
+def validation_summary(ds) -> Dict[str, int]:
+    """The whole-field numbers of ``_validate_data_values`` (computes the blocks' anomaly stage)."""
+    v = ds.attrs["validation"]
+    return v.compute() if hasattr(v, "compute") else dict(v)
+
+
+def raise_if_invalid(ds) -> None:
+    """Raise the reference's ``DataValidationError`` texts (detect.py:224-279) from the reduced counts."""
+    _raise_if_invalid(_ShapeOnly(ds.attrs["_field_shape"]), validation_summary(ds))

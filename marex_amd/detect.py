@@ -603,8 +603,15 @@ def preprocess_data(
     quiet: Optional[bool] = None,
     device: int = 0,
     devices: Optional[List[int]] = None,
+    _validation: str = "raise",
+    _own_rows: Optional[Tuple[int, int]] = None,
 ):
     """Anomalies, thresholds and the boolean extreme mask of a (time, [lat,] lon / cells) field.
+
+    ``_validation="return"`` (internal: :mod:`marex_amd.dask_adapter` runs one spatial block of a larger field per call): the
+    verdict of ``_validate_data_values`` is not raised but returned as ``ds.attrs["_validation"]`` -- a block may be all land,
+    and the error is about the whole field; ``_own_rows=(r0, r1)``: the grid rows (cells on a mesh) of the block its counts
+    are about -- the others are overlap rows.
 
     ``devices=[0, 1, ...]`` (extension): the field is cut into at least that many spatial blocks (latitude bands
     with ``ws//2`` overlap rows / cell ranges -- cells are independent along time) and every listed device works through its
@@ -727,9 +734,12 @@ def preprocess_data(
 
         a = _anomaly_core(e, fb, method_anomaly, window_year_baseline, smooth_days_baseline, detrend_orders,
                           force_zero_mean, reference_period, bins_for)
-        part = _validation_summary(e, a, sh.own_cell_slice())
+        own_cells = sh.own_cell_slice()
+        if _own_rows is not None and single:
+            own_cells = slice(_own_rows[0] * (field.nx if field.gridded else 1), _own_rows[1] * (field.nx if field.gridded else 1))
+        part = _validation_summary(e, a, own_cells)
         res = {"part": part, "cal": a["cal"], "defer": defer, "n_true": 0, "kinds": {}}
-        if part["max_invalid"] > 0 or stop["bad"] or (single and part["n_ocean"] == 0):
+        if _validation == "raise" and (part["max_invalid"] > 0 or stop["bad"] or (single and part["n_ocean"] == 0)):
             stop["bad"] = stop["bad"] or part["max_invalid"] > 0
             return res  # the run ends in the reference's validation error: only the counts of the other blocks matter
         ext, thr, thr_kind, n_true = _extremes_core(
@@ -799,7 +809,8 @@ def preprocess_data(
         kinds.update(res["kinds"])
         n_true_total += res["n_true"]
         cal = res["cal"]
-    _raise_if_invalid(field, total)
+    if _validation == "raise":
+        _raise_if_invalid(field, total)
     if method_anomaly == "shifting_baseline":
         logger.info(f"Trimming data to start from {cal.min_year + window_year_baseline} (removing first {window_year_baseline} years)")
     # the reference's two threshold-range warnings, once per threshold array (detect.py:2711-2730)
@@ -866,6 +877,8 @@ def preprocess_data(
     if method_extreme == "hobday_extreme":
         ds.attrs["window_days_hobday"] = window_days_hobday
     ds.attrs.update({"method_percentile": method_percentile, "precision": precision, "max_anomaly": max_anomaly})
+    if _validation != "raise":
+        ds.attrs["_validation"] = dict(total)
     logger.info(f"Preprocessing completed successfully - {n_true_total} extreme events identified")
     return ds
 
