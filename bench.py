@@ -405,7 +405,19 @@ def main():
             "mask": cown * (4 * T_out + T_out + 4 * 366),
             "transpose": cin * 8 * 366,
         }
-        dom = max(kern, key=lambda k: kern[k][0])
+        # With the bands on several streams a launch's HIP-event time includes what the neighbouring streams' kernels take: the
+        # roofline object then speaks about a single-stream pass of the same step in this same run (every band on one engine,
+        # kernels one after the other) and keeps the timed region's averages beside it
+        serial = None
+        if eset is not None and world == 1 and not args.no_extra:
+            try:
+                serial = serial_extra(hot, shards, xs, dcal, step_kw, detrend, T * (ny_total * nx if ny_total else nx * world) / 1e6,
+                                      eset.workspaces[0])
+            except Exception as e:  # noqa: BLE001
+                serial = {"error": f"{type(e).__name__}: {e}"[:300]}
+                torch.cuda.empty_cache()
+        per_launch = serial["kernel_ms"] if serial and serial.get("kernel_ms") else None
+        dom = max(per_launch, key=per_launch.get) if per_launch else max(kern, key=lambda k: kern[k][0])
         # HBM bytes of the dominant kernel from the committed PMC passes of this same command (profiles/)
         traffic = None
         lean = (path == "tails" and detrend is None and step_kw["S"] == 21 and step_kw["W"] in (5, 15) and shard.cells_in % 4 == 0
@@ -421,7 +433,8 @@ def main():
                     if name.startswith(kname):
                         traffic = rec["hbm_bytes"]
         avg_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in kern.items()}
-        achieved = per_kernel_alg[dom] / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] else 0.0
+        dom_ms = per_launch[dom] if per_launch else avg_ms[dom]
+        achieved = per_kernel_alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
         out = {
             "metric": "Mcells*timesteps/s, shifting_baseline + hobday_extreme p95 (validation+anomaly+thresholds+mask)",
             "value": value,
@@ -456,10 +469,10 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "avg_launch_ms": avg_ms[dom],
+                "avg_launch_ms": dom_ms,
                 "algorithmic_bytes_per_launch": per_kernel_alg[dom],
-                "timing": ("HIP events on each engine's stream over the timed region" +
-                           (f"; {nstream} streams share the GPU, so a launch's duration includes what its neighbours take" if nstream > 1 else "")),
+                "timing": ("HIP events on the launch stream, single-stream pass of the same step inside this run (extra.single_stream)"
+                           if per_launch else "HIP events on the launch stream over the timed region"),
             },
             "pipeline_roofline": {
                 "algorithmic_bytes_per_step_per_gpu": b_alg_rank,
@@ -474,24 +487,14 @@ def main():
             # untimed additions: a failure here (say, no room left for another workspace) must not cost the line
             out["extra"] = {}
             wsp0 = eset.workspaces[0] if eset is not None else workspace
-            if eset is not None:  # before the seasonal line: that one overwrites band 0
-                try:
-                    se = serial_extra(hot, shards, xs, dcal, step_kw, detrend, units, wsp0)
-                    out["extra"]["single_stream"] = se
-                    if se["kernel_ms"].get(dom):
-                        # the kernel's own duration: with the bands on several streams a launch's HIP-event time includes what the
-                        # neighbouring stream's kernels take, so the roofline object speaks about the single-stream pass of the same
-                        # step in this same run and keeps the timed region's averages beside it
-                        a1 = per_kernel_alg[dom] / (se["kernel_ms"][dom] * 1e-3) / 1e9
-                        rf = out["roofline"]
-                        rf["timed_region"] = {"avg_launch_ms": rf["avg_launch_ms"], "achieved": rf["achieved"], "frac": rf["frac"],
-                                              "note": rf["timing"]}
-                        rf.update({"avg_launch_ms": se["kernel_ms"][dom], "achieved": a1, "frac": a1 / HBM_PEAK_GBS,
-                                   "timing": "HIP events on the launch stream, single-stream pass of the same step inside this run "
-                                             "(extra.single_stream); timed_region = the same launches while a second stream shares the GPU"})
-                except Exception as e:  # noqa: BLE001
-                    out["extra"]["single_stream"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-                    torch.cuda.empty_cache()
+            if serial is not None:
+                out["extra"]["single_stream"] = serial
+                if per_launch and avg_ms.get(dom):
+                    a_t = per_kernel_alg[dom] / (avg_ms[dom] * 1e-3) / 1e9
+                    out["roofline"]["timed_region"] = {
+                        "avg_launch_ms": avg_ms[dom], "achieved": a_t, "frac": a_t / HBM_PEAK_GBS,
+                        "note": f"HIP events on each engine's stream over the timed region; {nstream} streams share the GPU, so a "
+                                "launch's duration includes what its neighbours take"}
             if detrend is None:
                 try:
                     base_ms = out["extra"].get("single_stream", {}).get("kernel_ms") or avg_ms

@@ -249,17 +249,19 @@ def shard_step(hot, shards, xs, dcal, *, W: int = 15, S: int = 21, bins, q: floa
     return r, local, mx
 
 
-def broadcast_tables(tables: Optional[Dict[str, object]], src: int = 0, device=None, host_collectives: bool = False) -> Dict[str, object]:
+def broadcast_tables(tables: Optional[Dict[str, object]], src: int = 0, device=None, host_collectives: bool = False,
+                     force: bool = False) -> Dict[str, object]:
     """The host-built tables of a run -- calendar plan arrays, bin edges / centres, detrend model and pseudo-inverse -- from rank
     ``src`` to every rank ("ncclBroadcast of calendar tables + bin edges/centres + pinv rows"): one object
     broadcast of the manifest (names, dtypes, shapes, scalars), one byte broadcast of the packed arrays (a device tensor over
     RCCL; ``host_collectives``: a host tensor over gloo).  ``tables`` maps names to NumPy arrays or plain scalars and is only
     read on ``src``; every rank gets the same dict back, ``src`` included (its own arrays go through the same packing, so all
-    ranks work from identical bytes).  Without a process group the input is returned as it is."""
+    ranks work from identical bytes).  Without a process group -- or with a single rank, unless ``force`` asks for the collectives
+    all the same (tests) -- the input is returned as it is."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return dict(tables or {})
     rank = dist.get_rank()
     manifest, chunks, off = None, [], 0

@@ -16,7 +16,7 @@ import torch
 
 import marex_amd
 from marex_amd import binning, calendar, synth
-from marex_amd.dist import allreduce_step, gather_owned_cells, plan_shards, shard_step, stitch_cells
+from marex_amd.dist import EngineSet, allreduce_step, broadcast_tables, gather_owned_cells, plan_shards, shard_step, stitch_cells
 from marex_amd.xr_compat import DataArray
 from oracle import marex_oracle as orc
 
@@ -100,5 +100,18 @@ def test_shard_step_with_rccl_collectives(hot):
         assert np.array_equal(stitch_cells(ext_parts, shards).astype(bool), ref["extreme_events"])
         v = orc.validate_data_values(x_full)
         assert [int(t) for t in tot[:4]] == [v["n_ocean"], v["total_invalid_in_ocean"], v["locations_affected"], int(ref["extreme_events"].sum())]
+        # the tables of a run through the RCCL broadcast (object manifest + one device byte tensor), as bench.py's ranks get them
+        tables = calendar.plan_tables(cal)
+        tables.update({"bins.edges": bt.edges, "bins.centres": bt.centres, "bins.precision": 0.01})
+        got = broadcast_tables(tables, src=0, device=torch.device("cuda", hot.device.index), force=True)
+        cal2 = calendar.plan_from_tables(got)
+        assert np.array_equal(cal2.year_plan(), cal.year_plan()) and cal2.T_out == cal.T_out and cal2.kept.dtype == np.bool_
+        assert got["bins.edges"].tobytes() == bt.edges.tobytes() and got["bins.precision"] == 0.01
+        # and the multi-stream schedule of a rank with several bands, reduced over RCCL
+        es = EngineSet(hot.device.index, 2)
+        r2, local2, mx2 = shard_step(es, shards, xs, cal2, W=W, S=21, bins=bt, q=0.95, wd=11, ws=5, nx=nx)
+        local2, mx2 = allreduce_step(local2, mx2)
+        torch.cuda.synchronize()
+        assert [int(t) for t in local2[:4]] == [int(t) for t in tot[:4]]
     finally:
         dist.destroy_process_group()

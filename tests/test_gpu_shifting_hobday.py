@@ -191,3 +191,34 @@ def test_tall_tile_for_bands_it_tiles_better(hot, path, ny, nx, opts):
     rows: one row of tiles instead of two; same bits as the oracle, also on the exact path and with short day blocks."""
     r = run_case(hot, "2001-01-01", 8 * 365 + 2, ny, nx, 3, 21, 11, 5, path=path, opts=dict(opts, THR_TILE=32))
     check_all(*r)
+
+
+@pytest.mark.parametrize("W,years,start,nx", [(15, 40, "1980-01-01", 66), (5, 23, "2001-03-17", 52), (15, 33, "1990-07-01", 64)])
+def test_lean_and_fast_anomaly_kernels_agree_on_awkward_fields(hot, W, years, start, nx):
+    """k_shift_lean (lean records, straight-line body for regular years, LDS-DMA staging) against k_shift_fast (SHIFT_LEAN=0) on
+    calendars and fields that leave the straight-line body: mid-year starts, a partial last cell group, gaps, a late-starting
+    cell, values beyond the table, +-inf.  Same anomalies, counts, lists and aux words, bit for bit."""
+    tm = calendar.daily_time_axis(start, years * 365 + years // 4)
+    x = synth.synth_field(synth.make_tables(tm, 3, nx))
+    ocean = np.flatnonzero(np.isfinite(x[0]))
+    x[400:430, ocean[0]] = np.nan                      # a gap: NaN in the history for W years
+    x[: 6 * 365, ocean[1]] = np.nan                    # a cell that starts late
+    x[:, ocean[2]] += np.float32(40.0) * (np.arange(x.shape[0]) % 7 == 0)   # values beyond the table, several per bucket
+    x[1234, ocean[3]] = np.inf
+    x[2345, ocean[4]] = -np.inf
+    cal = calendar.build_calendar(tm, window_year_baseline=W)
+    dcal = hot.upload_calendar(cal)
+    bt = binning.hobday_bins()
+    xd = torch.from_numpy(x).to(hot.device)
+    res = {}
+    for lean in (1, 0):
+        with hot.ctx.options(SHIFT_LEAN=lean):
+            a = hot.shifting_baseline_tails(xd, dcal, W, 21, bt)
+            hot.sync()
+        res[lean] = {k: a[k].cpu().numpy() for k in ("out", "mask", "invalid_count")}
+        res[lean]["tails"] = a["tails"]["tails"].cpu().numpy()
+        res[lean]["aux"] = a["tails"]["aux"].cpu().numpy()
+    for k in res[1]:
+        assert np.array_equal(res[1][k], res[0][k], equal_nan=res[1][k].dtype.kind == "f"), k
+    exp, mask = orc.shifting_baseline_anomaly(x, cal, W, 21)
+    assert np.array_equal(res[1]["out"], exp, equal_nan=True) and np.array_equal(res[1]["mask"].astype(bool), mask)
