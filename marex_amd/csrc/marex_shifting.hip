@@ -386,7 +386,7 @@ __device__ __forceinline__ void tl_out_store(tl_out_rsrc_t r, unsigned voff, uns
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     const u4 v = {w[0], w[1], w[2], w[3]};
     const int soff_u = __builtin_amdgcn_readfirstlane((int)soff);
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 2" : : "v"(v), "v"(voff), "s"(r), "s"(soff_u) : "memory");
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 2" : : "v"(v), "v"(voff), "s"(r), "s"(soff_u) : "memory");
 }
 
 
@@ -1198,6 +1198,36 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
     // the centre rows H .. H+3, the part that the pairs of half P feed
     auto half = [&](auto Pc) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value, M0 = P ? NH0 : 0, M1 = P ? NPAIR : NH0;
+        if constexpr (S == 21) {
+            // The two chains of a half as ONE block: a v_pk_add_f32 in its own asm statement (and, through an encoding alias of
+            // the op_sel_hi bit of src0 with VOP3's dst op_sel, every compiler-visible v_pk_add_f32 too) is taken for a producer
+            // of a partial register write, and the hazard recogniser puts an s_nop in front of its consumer -- 20 per year.
+            // v_pk_add_f32 writes two whole registers: there is no such hazard, and inside a block nothing is inserted.
+#define PK_LO(acc, src) "v_pk_add_f32 %" #acc ", %" #acc ", %" #src " op_sel_hi:[1,0]\n\t"
+#define PK_HI(acc, src) "v_pk_add_f32 %" #acc ", %" #acc ", %" #src " op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+#define PK_BOTH(src) PK_LO(0, src) PK_LO(1, src) PK_HI(0, src) PK_HI(1, src)
+            if (P == 0) {  // rows 0..11: chain A takes rows 1..11, chain B (starts at row 2) rows 3..11
+                accA = (v2f){xh[0].x, -0.0f};
+                accB = (v2f){xh[1].x, -0.0f};
+                asm(PK_HI(0, 2) PK_LO(0, 3) PK_HI(0, 3) PK_HI(1, 3) PK_BOTH(4) PK_BOTH(5) PK_BOTH(6) PK_BOTH(7)
+                    : "+v"(accA), "+v"(accB)
+                    : "v"(xh[0]), "v"(xh[1]), "v"(xh[2]), "v"(xh[3]), "v"(xh[4]), "v"(xh[5]));
+                xc0 = xh[5].x;  // centre rows H .. H+3 = 10 .. 13
+                xc1 = xh[5].y;
+            } else {  // rows 12..23: chain A rows 12..20 and its second lane row 21, chain B rows 12..22 and row 23
+                asm(PK_BOTH(2) PK_BOTH(3) PK_BOTH(4) PK_BOTH(5) PK_LO(0, 6) PK_LO(1, 6) PK_HI(1, 6) PK_LO(1, 7)
+                    : "+v"(accA), "+v"(accB)
+                    : "v"(xh[0]), "v"(xh[1]), "v"(xh[2]), "v"(xh[3]), "v"(xh[4]), "v"(xh[5]));
+                accA.y += xh[4].y;
+                accB.y += xh[5].y;
+                xc2 = xh[0].x;
+                xc3 = xh[0].y;
+            }
+#undef PK_BOTH
+#undef PK_HI
+#undef PK_LO
+            return;
+        }
         if (P == 0) accA = (v2f){xh[0].x, -0.0f};
 #pragma unroll
         for (int s = 1; s <= S - 1; ++s)
