@@ -437,6 +437,7 @@ struct DmaRows<7> {  // S = 11 (26 rows staged as 28): rows 0-3, 4, 5, 6
 
 #define SHIFT_INFO_WORDS 128  // [0..91] chunk handled by the fast kernel, [92] arange edges usable
 #define CLASSIFY_SPLIT 11      // threads per chunk in k_shift_classify (92 * 11 = 1012 <= 1024)
+#define LEAN_CHUNKS 96         // chunk slots per year of lean records (92 chunks, padded to whole workgroups of 8 waves)
 
 // fplan[year][chunk] = two int4: {timestep of the chunk's first dayofyear (-1: absent), its output row (-1: none), number of
 // leading dayofyears present (0..4), bin-matrix row of dayofyear 0} and {bin-matrix rows of dayofyears 1..3, timestep of the
@@ -449,7 +450,7 @@ struct DmaRows<7> {  // S = 11 (26 rows staged as 28): rows 0-3, 4, 5, 6
 // position of their buckets.
 __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, const float* __restrict__ edges, int nb,
                                  int want_bins, int enable, int* __restrict__ info, int4* __restrict__ fplan, long T, long C,
-                                 int reg_S, int4* __restrict__ lplan, const int* __restrict__ doy_start) {
+                                 int reg_S, int4* __restrict__ lplan, const int* __restrict__ doy_start, int wpb) {
     __shared__ int s_edges_ok;
     const int t = threadIdx.x;
     int eok = 1;
@@ -508,8 +509,9 @@ __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, 
     }
     __syncthreads();
     if (chunk < 92 && lplan && reg_S > 0) {  // lean records of years -1 .. n_cal
-        const int H = reg_S / 2, NPAIR = (reg_S + 3) / 2, NROWS = 4 * ((reg_S + 15 + 3) / 4);
-        const int d0 = chunk * 4, blk16 = (chunk >> 2) * 16;
+        // wpb = waves (chunks of 4 dayofyears) per workgroup of the lean kernel: 4 or 8
+        const int H = reg_S / 2, NPAIR = (reg_S + 3) / 2, NROWS = wpb * ((reg_S + 4 * wpb - 1 + wpb - 1) / wpb);
+        const int d0 = chunk * 4, blk16 = (chunk / wpb) * wpb * 4;
         for (int yy = sub - 1; yy <= n_cal; yy += CLASSIFY_SPLIT) {
             int flags = 0, tbv = -1, pos = 0;
             long long xoff = 0, ooff = 0;
@@ -525,7 +527,7 @@ __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, 
                 for (int i = 0; i < 4; ++i) e[i] = (d0 + i < NDOY) ? year_plan[(size_t)yy * NDOY + d0 + i] : make_int4(-1, -1, -1, 0);
                 tbv = year_plan[(size_t)yy * NDOY + blk16].x;
                 int reg = d0 + 3 < NDOY && e[0].x >= 0 && e[1].x >= 0 && e[2].x >= 0 && e[3].x >= 0;
-                reg = reg && tbv >= H && (long)tbv - H + NROWS <= T && e[0].x == tbv + 4 * (chunk & 3);
+                reg = reg && tbv >= H && (long)tbv - H + NROWS <= T && e[0].x == tbv + 4 * (chunk % wpb);
                 reg = reg && e[0].x - H >= 0 && (long)e[0].x - H + 2 * NPAIR <= T;
                 for (int i = 1; i < 4; ++i) reg = reg && e[i].x == e[0].x + i && ((e[0].y >= 0) == (e[i].y >= 0));
                 if (e[0].y >= 0) {
@@ -537,9 +539,15 @@ __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, 
                 }
                 if (reg) flags |= 1;  // LR_REG
             }
-            int4* r = lplan + ((size_t)(yy + 1) * 92 + chunk) * 2;
+            int4* r = lplan + ((size_t)(yy + 1) * LEAN_CHUNKS + chunk) * 2;
             r[0] = make_int4(flags, tbv, (int)(unsigned)(xoff & 0xFFFFFFFFll), (int)(unsigned)((unsigned long long)xoff >> 32));
             r[1] = make_int4((int)(unsigned)(ooff & 0xFFFFFFFFll), (int)(unsigned)((unsigned long long)ooff >> 32), pos, 0);
+            // the waves of the last workgroup that have no dayofyears (chunks 92..95 with 8 waves) only help staging: the
+            // workgroup's part of the record, nothing of a chunk
+            if (chunk + 4 >= 92 && chunk + 4 < (92 + wpb - 1) / wpb * wpb) {
+                r[8] = make_int4(flags & 4, tbv, (int)(unsigned)(xoff & 0xFFFFFFFFll), (int)(unsigned)((unsigned long long)xoff >> 32));
+                r[9] = make_int4(0, 0, 0, 0);
+            }
         }
     }
     if (t < 92) info[t] = s_ok[t] && s_edges_ok;
@@ -1048,8 +1056,8 @@ __device__ __forceinline__ void unroll_steps(F&& f) {
 #define LR_OUT 2         // an output year
 #define LR_STAGE_NEXT 4  // next year's rows of the workgroup can be staged (the block lies inside the series)
 
-template <int W, int S>
-__global__ void __launch_bounds__(256, 4)  // four workgroups per CU: at most 128 VGPRs
+template <int W, int S, int NWV>  // NWV waves = 4 NWV dayofyears per workgroup: 4 (36 rows staged for 16) or 8 (52 for 32)
+__global__ void __launch_bounds__(64 * NWV, 16 / NWV)  // sixteen waves per CU: at most 128 VGPRs
 k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__ fplan, const int4* __restrict__ lplan, int n_cal,
              const int* __restrict__ info, const float* __restrict__ edges, int nb, float* __restrict__ out,
              unsigned char* __restrict__ mask, int* __restrict__ invalid_count, int ncg, int nblk, TailOut tails) {
@@ -1057,15 +1065,16 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
     if (!xcd_swizzle(blockIdx.x, ncg, nblk, cg, bc)) return;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
-    const int chunk = bc * 4 + wave;
+    const int chunk = bc * NWV + wave;
     static_assert((S & 1) == 1 && S >= 5 && S <= 25, "k_shift_lean: odd smoothing widths 5..25");
-    constexpr int H = S / 2, NPAIR = (S + 3) / 2, NST = S + 15, RPW = (NST + 3) / 4;
+    static_assert(NWV == 4 || NWV == 8, "k_shift_lean: 4 or 8 waves");
+    constexpr int H = S / 2, NPAIR = (S + 3) / 2, NST = S + 4 * NWV - 1, RPW = (NST + NWV - 1) / NWV;
     // the rows of a year go from memory straight into the stage by LDS-DMA (DmaRows above: three instructions per wave instead of
     // nine loads and nine ds_write, and no registers held by a prefetched year); every wave issues the same instructions, so
-    // the stage has 4 RPW rows
-    constexpr int NROWS = 4 * RPW;
+    // the stage has NWV RPW rows
+    constexpr int NROWS = NWV * RPW;
     __shared__ float stage[NROWS * 64];
-    __shared__ unsigned newkeys[4][2][SHIFT_LIST][64];  // [wave][pair of dayofyears][year slot][lane]
+    __shared__ unsigned newkeys[NWV][2][SHIFT_LIST][64];  // [wave][pair of dayofyears][year slot][lane]
     const bool mine = chunk < 92 && info[chunk] != 0;  // wave-uniform; the other waves only help staging
     const int d0 = mine ? chunk * 4 : 0;
     const int c = cg * 64 + lane;
@@ -1095,7 +1104,7 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
         const unsigned long long off = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
         DmaRows<RPW>::issue(tl_out_make_rsrc(xw + off), dma_voff4, voff, dma_lds, 256u, 0u, (unsigned)rowb);
     };
-    constexpr int LSTRIDE = 92 * 2;  // int4 per year of lean records
+    constexpr int LSTRIDE = LEAN_CHUNKS * 2;  // int4 per year of lean records
     const int4* lr_next = lplan + (size_t)chunk * 2;  // "year -1"
     {
         const int4 pre = lr_next[0];
@@ -1495,6 +1504,7 @@ struct ShiftArgs {
     TailOut tails;
     bool lean = false;  // k_shift_lean takes the tails configuration
     const int4* lplan = nullptr;  // its lean records
+    int lean_waves = 4;           // waves per workgroup of k_shift_lean (option SHIFT_LEAN_WAVES)
 };
 
 template <int D, int SCAP, bool SEXACT, int WCAP, bool RREG>
@@ -1518,9 +1528,14 @@ static void launch_shift_fast(marex_ctx* ctx, const ShiftArgs& a) {
     const int ncg = (int)((a.C + 63) / 64);
 #define MAREX_SF_ARGS dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C, a.fplan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask, a.invalid_count, ncg, 23, a.tails
     if (a.tails.lists && a.lean) {
-        if constexpr (S == 21 && (W == 15 || W == 5))
-            hipLaunchKernelGGL((k_shift_lean<W, S>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (int)a.T, (int)a.C, a.fplan,
-                               a.lplan, a.n_cal, a.skip, a.edges, a.nb, a.out, a.mask, a.invalid_count, ncg, 23, a.tails);
+        if constexpr (S == 21 && (W == 15 || W == 5)) {
+            if (a.lean_waves == 8)
+                hipLaunchKernelGGL((k_shift_lean<W, S, 8>), dim3(xcd_grid(ncg, 12)), dim3(512), 0, ctx->stream, a.x, (int)a.T, (int)a.C, a.fplan,
+                                   a.lplan, a.n_cal, a.skip, a.edges, a.nb, a.out, a.mask, a.invalid_count, ncg, 12, a.tails);
+            else
+                hipLaunchKernelGGL((k_shift_lean<W, S, 4>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (int)a.T, (int)a.C, a.fplan,
+                                   a.lplan, a.n_cal, a.skip, a.edges, a.nb, a.out, a.mask, a.invalid_count, ncg, 23, a.tails);
+        }
     } else if (a.tails.lists) {
         // LDS-DMA staging + L2 prefetch (option SHIFT_DMA=1; measured round 3 on a 100-yr band: 12.17 ms against 11.84 ms with
         // the rows staged through VGPRs -- the kernel is bound by instruction issue, not by the latency of its loads -- so it
@@ -1587,7 +1602,8 @@ static int shifting_impl(marex_ctx* ctx, const char* who, const float* x, int64_
     if (fast_cfg) {
         // the lean kernel stages its rows by LDS-DMA: whole 16-byte segments of a row inside the field or beyond it (C % 4 == 0)
         const bool lean = tails.lists && lean_instance(W, S) && ctx_opt(ctx, "SHIFT_LEAN", 1) != 0 && C >= 4 && C % 4 == 0 &&
-                          T < (1ll << 31) - 64 && (unsigned long long)(4 * ((S + 18) / 4) + 4) * (unsigned long long)C * 4ull < 0xFFFFFFFFull;
+                          T < (1ll << 31) - 64 && (unsigned long long)(S + 31 + 8 + 4) * (unsigned long long)C * 4ull < 0xFFFFFFFFull;
+        const int lean_waves = ctx_opt(ctx, "SHIFT_LEAN_WAVES", 4) == 8 ? 8 : 4;
         if (lean && ctx->shift_lplan_years < (size_t)n_cal_years) {
             if (ctx->shift_lplan) {
                 HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1595,12 +1611,13 @@ static int shifting_impl(marex_ctx* ctx, const char* who, const float* x, int64_
                 ctx->shift_lplan = nullptr;
                 ctx->shift_lplan_years = 0;
             }
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->shift_lplan, ((size_t)n_cal_years + 2) * 92 * 8 * sizeof(int)));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->shift_lplan, ((size_t)n_cal_years + 2) * LEAN_CHUNKS * 8 * sizeof(int)));
             ctx->shift_lplan_years = (size_t)n_cal_years;
         }
         hipLaunchKernelGGL(k_shift_classify, dim3(1), dim3(1024), 0, ctx->stream, a.year_plan, n_cal_years, edges, nb,
                            (bins || tails.lists) ? 1 : 0, 1, ctx->shift_info, reinterpret_cast<int4*>(ctx->shift_plan), (long)T, (long)C,
-                           lean ? S : 0, lean ? reinterpret_cast<int4*>(ctx->shift_lplan) : nullptr, tails.doy_start);
+                           lean ? S : 0, lean ? reinterpret_cast<int4*>(ctx->shift_lplan) : nullptr, tails.doy_start, lean_waves);
+        a.lean_waves = lean_waves;
         a.lplan = reinterpret_cast<const int4*>(ctx->shift_lplan);
         a.lean = lean;
         a.skip = ctx->shift_info;

@@ -352,7 +352,8 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
     auto apply_bucket = [&](const Pre& pr, int sgn) {
         if (cell_valid) {
 #pragma unroll
-            for (int u = 0; u < TB_PRE; ++u) bump(pr.b[u], sgn);
+            for (int u = 0; u < TB_PRE; ++u)
+                if (u < pr.nd) bump(pr.b[u], sgn);  // uniform: a 5-sample bucket (10-yr series) is 5 updates, not 8
         }
         if (pr.nd > TB_PRE) {  // long buckets (many years): stream the rest, TB_BATCH loads in flight
             const unsigned short* col = colbase + (size_t)pr.r0 * 16;
