@@ -1321,6 +1321,29 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
         constexpr int J = decltype(Jc)::value;
         v2f smA, smB, xcA, xcB;
         smooth(cA, smA, smB, xcA, xcB, 0, 0);
+        // A wave whose 64 cells are all NaN on the 4 centre rows (land: 16 % of the cell groups of the 0.25-degree benchmark
+        // field) has nothing to compute this year: the anomalies are the NaNs themselves, no key is counted.  Decided on the
+        // values, year by year (a cell that is NaN today may hold numbers next year).
+        const bool dead = __builtin_amdgcn_ballot_w64(xcA.x == xcA.x || xcA.y == xcA.y || xcB.x == xcB.x || xcB.y == xcB.y) == 0;
+        if (dead) {
+            n_invalid += 4;
+            if (cA.x & LR_OUT) {
+                newkeys[wave][0][t_slot][lane] = 0u;
+                newkeys[wave][1][t_slot][lane] = 0u;
+                ++t_slot;
+                const unsigned long long ooff = ((unsigned long long)(unsigned)cB.y << 32) | (unsigned)cB.x;
+                const rsrc_t ro = make_rsrc(reinterpret_cast<char*>(out) + ooff);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (active) {  // NaN - climatology = the (quieted) NaN itself
+                    stb_f32(ro, voff, 0, __builtin_canonicalizef(xcA.x));
+                    stb_f32(ro, voff, rowb, __builtin_canonicalizef(xcA.y));
+                    stb_f32(ro, voff, 2 * rowb, __builtin_canonicalizef(xcB.x));
+                    stb_f32(ro, voff, 3 * rowb, __builtin_canonicalizef(xcB.y));
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
         n_invalid += (finite_f(xcA.x) ? 0 : 1) + (finite_f(xcA.y) ? 0 : 1) + (finite_f(xcB.x) ? 0 : 1) + (finite_f(xcB.y) ? 0 : 1);
         if (cA.x & LR_OUT) {
             v2f aA, aB;
@@ -1358,6 +1381,7 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         }
         hA[J + W] = smA;  // year y joins the history
         hB[J + W] = smB;
@@ -1504,7 +1528,7 @@ struct ShiftArgs {
     TailOut tails;
     bool lean = false;  // k_shift_lean takes the tails configuration
     const int4* lplan = nullptr;  // its lean records
-    int lean_waves = 4;           // waves per workgroup of k_shift_lean (option SHIFT_LEAN_WAVES)
+    int lean_waves = 4;           // waves per workgroup of k_shift_lean
 };
 
 template <int D, int SCAP, bool SEXACT, int WCAP, bool RREG>
@@ -1529,11 +1553,8 @@ static void launch_shift_fast(marex_ctx* ctx, const ShiftArgs& a) {
 #define MAREX_SF_ARGS dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C, a.fplan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask, a.invalid_count, ncg, 23, a.tails
     if (a.tails.lists && a.lean) {
         if constexpr (S == 21 && (W == 15 || W == 5)) {
-            if (a.lean_waves == 8)
-                hipLaunchKernelGGL((k_shift_lean<W, S, 8>), dim3(xcd_grid(ncg, 12)), dim3(512), 0, ctx->stream, a.x, (int)a.T, (int)a.C, a.fplan,
-                                   a.lplan, a.n_cal, a.skip, a.edges, a.nb, a.out, a.mask, a.invalid_count, ncg, 12, a.tails);
-            else
-                hipLaunchKernelGGL((k_shift_lean<W, S, 4>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (int)a.T, (int)a.C, a.fplan,
+            // (NWV = 8 -- 52 rows staged for 32 dayofyears -- measured 11.2 ms against 10.0 per 100-yr band and is not instantiated)
+            hipLaunchKernelGGL((k_shift_lean<W, S, 4>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (int)a.T, (int)a.C, a.fplan,
                                    a.lplan, a.n_cal, a.skip, a.edges, a.nb, a.out, a.mask, a.invalid_count, ncg, 23, a.tails);
         }
     } else if (a.tails.lists) {
@@ -1603,7 +1624,7 @@ static int shifting_impl(marex_ctx* ctx, const char* who, const float* x, int64_
         // the lean kernel stages its rows by LDS-DMA: whole 16-byte segments of a row inside the field or beyond it (C % 4 == 0)
         const bool lean = tails.lists && lean_instance(W, S) && ctx_opt(ctx, "SHIFT_LEAN", 1) != 0 && C >= 4 && C % 4 == 0 &&
                           T < (1ll << 31) - 64 && (unsigned long long)(S + 31 + 8 + 4) * (unsigned long long)C * 4ull < 0xFFFFFFFFull;
-        const int lean_waves = ctx_opt(ctx, "SHIFT_LEAN_WAVES", 4) == 8 ? 8 : 4;
+        const int lean_waves = 4;
         if (lean && ctx->shift_lplan_years < (size_t)n_cal_years) {
             if (ctx->shift_lplan) {
                 HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -222,3 +222,24 @@ def test_lean_and_fast_anomaly_kernels_agree_on_awkward_fields(hot, W, years, st
         assert np.array_equal(res[1][k], res[0][k], equal_nan=res[1][k].dtype.kind == "f"), k
     exp, mask = orc.shifting_baseline_anomaly(x, cal, W, 21)
     assert np.array_equal(res[1]["out"], exp, equal_nan=True) and np.array_equal(res[1]["mask"].astype(bool), mask)
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_cell_groups_that_are_all_nan_for_some_years(hot, path):
+    """The lean anomaly kernel skips the arithmetic of a wave-year whose 64 cells are all NaN on the centre rows.  Whole groups
+    of 64 consecutive cells that are NaN from the start and come alive later, that fall silent for a few years in the middle,
+    that are NaN on single days only (not skipped: neighbours of the centre rows), and plain land -- same bits as the oracle."""
+
+    def mutate(x):
+        T, C = x.shape
+        assert C >= 256
+        x[: 7 * 365 + 100, 0:64] = np.nan            # a group that starts late (NaN history, then nanmean years)
+        x[9 * 365 : 12 * 365 + 17, 64:128] = np.nan  # a group with a three-year gap in the middle
+        x[:, 128:192] = np.nan                       # land
+        x[4000:4003, 192:256] = np.nan               # three days only: the years around them are not all-NaN on their centre rows
+        x[5000, 192:256:2] = np.inf
+
+    r = run_case(hot, "1991-01-01", 22 * 365 + 5, 4, 80, 5, 21, 11, 5, mutate=mutate, path=path)
+    check_all(*r)
+    r = run_case(hot, "1986-01-01", 34 * 365 + 8, 4, 80, 15, 21, 11, 5, mutate=mutate, path=path)
+    check_all(*r)
