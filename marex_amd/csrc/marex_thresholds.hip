@@ -234,6 +234,9 @@ k_thresholds(const unsigned short* __restrict__ bins, long T_out, long C, int ny
 #define TB_LS 34
 #define TB_DMAX 32
 #define TB_PRE 8
+#ifndef TB_ROWWIN
+#define TB_ROWWIN 16  // levels a tile row reads at once in the row-pooled search
+#endif
 #ifndef TB_BATCH
 #define TB_BATCH 16
 #endif
@@ -453,6 +456,38 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         Wv[6] = (int)(a3 & 0xFFFFu);
         Wv[7] = (int)(a3 >> 16);
     };
+    // ---- TC == 16: a tile row is a DPP row of the wave.  The pooled count of a lane is then a VERTICAL sum in its own tile
+    // column (2P+1 reads) followed by a HORIZONTAL sum across the row with row_shr / row_shl (zero beyond the row: halo
+    // columns never ask) -- 5 + 4 instead of 25 reads and adds per dword, provided the lanes of a row look at the same levels.
+    constexpr bool ROWPOOL = TC == 16 && TR > 1 && P >= 1 && P <= 3 && NT == 256;
+    auto row_sum = [&](unsigned v) -> unsigned {
+        unsigned h = v;
+        if constexpr (P >= 1) {
+            h += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+            h += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true);
+        }
+        if constexpr (P >= 2) {
+            h += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+            h += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xF, 0xF, true);
+        }
+        if constexpr (P >= 3) {
+            h += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xF, 0xF, true);
+            h += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x103, 0xF, 0xF, true);
+        }
+        return h;
+    };
+    auto row_min = [&](int m) -> int {  // minimum over the 16 lanes of the row, in every lane
+        int o;
+        o = __builtin_amdgcn_update_dpp(m, m, 0x128, 0xF, 0xF, false); m = o < m ? o : m;
+        o = __builtin_amdgcn_update_dpp(m, m, 0x124, 0xF, 0xF, false); m = o < m ? o : m;
+        o = __builtin_amdgcn_update_dpp(m, m, 0x122, 0xF, 0xF, false); m = o < m ? o : m;
+        o = __builtin_amdgcn_update_dpp(m, m, 0x121, 0xF, 0xF, false); m = o < m ? o : m;
+        return m;
+    };
+    // tile cell whose column a lane sums vertically: its own, rows clamped into the part of the tile that has 2P+1 rows around
+    // it (lanes of halo rows compute something nobody reads)
+    const int trs = tr < P ? P : (tr > TR - 1 - P ? TR - 1 - P : tr);
+    const int cis = trs * TC + tc;
     // Smallest level k < khi whose pooled cumulative count exceeds qpos (khi if none); ck = that count,
     // cb = the count at k-1 (0 for k == 0).  Counts are integers, so "count <= qpos" is the integer test
     // "count <= floor(qpos)".  The 8-level window starts two levels below the hint (previous day's level)
@@ -508,6 +543,10 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
 
     // exact threshold of one output-day from level k of the current band (ck = cs[iu], cb = cs[iu-1])
     auto emit_threshold = [&](int d, int iu, int ck, int cb, double qpos) {
+        if (ablate & 16) {  // timing only: no table look-ups, no float64 interpolation
+            thr[(size_t)d * C + cell] = (float)(iu + ck + cb);
+            return;
+        }
         const int il = iu > 0 ? iu - 1 : 0;
         const int cs_iu = ck;
         const int cs_il = iu > 0 ? cb : ck;
@@ -597,6 +636,97 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
                     } else if (init_pd == pd) {
                         gst[dg][t] = 255;
                         thr[(size_t)d * C + cell] = nan_f();  // empty window
+                    }
+                }
+            } else if (mode == 1 && ROWPOOL) {
+                const bool need = g != 255;
+                if (__builtin_amdgcn_ballot_w64(need) != 0) {  // wave-uniform: all 64 lanes run the shared part
+                    unsigned tv = 0;
+#pragma unroll
+                    for (int dr = -P; dr <= P; ++dr) tv += tot_s[cis + dr * TC];
+                    const int tot = (int)row_sum(tv);
+                    const double qpos = q * (double)tot;
+                    if (hint < 0 && g < 254) hint = ((g - g_base) << shift) + 1 + (gsz >> 1);
+                    const bool want = need && tot > 0;
+                    // the window find_level would start from, per lane; the row reads 12 levels from the smallest of them
+                    const int khi = BW + 1;
+                    int top = (khi - 1) & ~3;
+                    top = top > 60 ? 60 : (top < 0 ? 0 : top);
+                    int start = ((hint >= 0 ? hint : ((1 + khi) >> 1)) - 2) & ~3;
+                    start = start < 0 ? 0 : (start > top ? top : start);
+                    constexpr int RW = TB_ROWWIN;  // levels the row reads at once (a multiple of 4)
+                    int u = row_min(want ? start : 0x7fffffff);
+                    u = u > 68 - RW ? 68 - RW : u;  // levels u .. u+RW-1 lie inside the 68-level column
+                    unsigned a[RW / 2];
+#pragma unroll
+                    for (int i = 0; i < RW / 2; ++i) a[i] = 0u;
+                    {
+                        const unsigned* base = &lev[cis * TB_LS] + (u >> 1);
+#pragma unroll
+                        for (int dr = -P; dr <= P; ++dr) {
+                            const uint2* p2 = reinterpret_cast<const uint2*>(base + dr * TC * TB_LS);
+#pragma unroll
+                            for (int i = 0; i < RW / 4; ++i) {
+                                const uint2 w = p2[i];
+                                a[2 * i] += w.x;
+                                a[2 * i + 1] += w.y;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < RW / 2; ++i) a[i] = row_sum(a[i]);
+                    int k = -1, ck = 0, cb = 0;
+                    bool solved = false;
+                    if (want) {
+                        const int qf = (int)floor(qpos);
+                        const int mm = (khi - u) < RW ? (khi - u) : RW;  // levels >= khi do not exist
+                        int Wv[RW];
+#pragma unroll
+                        for (int i = 0; i < RW; ++i) Wv[i] = (int)((a[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
+                        int n = 0;
+#pragma unroll
+                        for (int i = 0; i < RW; ++i) n += (i < mm) && (Wv[i] <= qf);
+                        if (n == 0) {  // the level at or below u: known only at the bottom
+                            if (u == 0) {
+                                k = 0;
+                                ck = Wv[0];
+                                solved = true;
+                            }
+                        } else if (n == mm) {  // nothing in the window exceeds qpos: the end of the levels, or look higher
+                            if (mm < RW) {
+                                k = khi;
+#pragma unroll
+                                for (int i = 0; i < RW; ++i)
+                                    if (i == mm - 1) cb = Wv[i];
+                                solved = true;
+                            }
+                        } else {
+                            k = u + n;
+#pragma unroll
+                            for (int i = 0; i < RW; ++i) {
+                                if (i == n - 1) cb = Wv[i];
+                                if (i == n) ck = Wv[i];
+                            }
+                            solved = true;
+                        }
+                        if (!solved && !(ablate & 32)) k = find_level(hint, 1, khi, qpos, true, ck, cb);  // rare: the lane's own windows
+                    }
+                    if (need) {
+                        if (tot > 0) {
+                            const bool ok = k >= 1 && k <= BW;
+                            if (ok) {
+                                hint = k;
+                                emit_threshold(d, B0 + k - 1, ck, cb, qpos);
+                                gst[dg][t] = 255;
+                            } else {
+                                hint = -1;
+                                gst[dg][t] = 254;
+                                s_unres = 1;
+                            }
+                        } else {
+                            gst[dg][t] = 255;
+                            thr[(size_t)d * C + cell] = nan_f();
+                        }
                     }
                 }
             } else if (mode == 1) {
