@@ -14,7 +14,7 @@ over one synthetic field that is already resident in HBM.  Metric (BASELINE.json
 scaling).  Bands are ingested with ws//2 overlap rows per interior side (marex_amd/dist.py); the collectives
 are a broadcast of the host-built tables (calendar, bin edges / centres, detrend model) from rank 0 before the
 timed region and an all-reduce of a few int64 scalars per step.  A rank with several bands runs them round-robin
-over `--streams` engines with a HIP stream each (marex_amd.dist.EngineSet, default 2): the product schedule.
+over `--streams` engines with a HIP stream each (marex_amd.dist.EngineSet, default 3 when the workspaces fit): the product schedule.
 
 Prints ONE JSON line on rank 0.
 """
@@ -229,10 +229,24 @@ def spawn_ranks(n: int, argv) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
+    # a rank that dies leaves the others waiting in a collective: once one has failed, the rest (the processes started
+    # here, by their own handles) get a few seconds and are then ended
+    import time
+
+    rc, failed_at = 0, None
+    while any(pr.poll() is None for pr in procs):
+        for pr in procs:
+            code = pr.poll()
+            if code and not rc:
+                rc, failed_at = code, time.time()
+        if failed_at is not None and time.time() - failed_at > 10.0:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.terminate()
+            failed_at = time.time() + 1e9  # asked once
+        time.sleep(0.2)
     for pr in procs:
-        code = pr.wait()
-        rc = rc or code
+        rc = rc or (pr.returncode or 0)
     return rc
 
 
@@ -244,8 +258,8 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=20240607)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("MAREX_BENCH_STREAMS", "0")),
-                    help="engines (HIP streams) the bands of a rank alternate between; 0 = default (2, or 1 for a single band / "
-                         "the one-GPU rehearsal)")
+                    help="engines (HIP streams) the bands of a rank alternate between; 0 = default (3 when their workspaces fit beside "
+                         "the resident field, else 2; 1 for a single band / the one-GPU rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements (single-stream pass, seasonally drifting thresholds)")
     ap.add_argument("--hobday-path", default=None, choices=["tails", "bins"],
@@ -298,8 +312,8 @@ def main():
         ny_total = wl["ny"] * world
     shard = shards[0]
 
-    # default: three engines when their workspaces fit beside the resident input (measured on the 100-yr field: 143.6 ms with one
-    # stream, 133.5 with two, 131.5 with three), else two; one for a single band and for the one-GPU rehearsal of several ranks
+    # default: three engines when their workspaces fit beside the resident input (measured on the 100-yr field, round 3: 141.0 ms with one
+    # stream, 129.5-133.5 with two, 128.8-129.8 with three), else two; one for a single band and for the one-GPU rehearsal of several ranks
     nstream = args.streams if args.streams > 0 else (1 if (len(shards) == 1 or one_gpu) else 3)
     nstream = max(1, min(nstream, len(shards)))
     if args.streams <= 0 and nstream == 3:

@@ -119,7 +119,8 @@ SUMMARY_KEYS = ("n_ocean", "invalid_total", "invalid_cells", "n_extreme", "thr_t
 class EngineSet:
     """``n`` engines on ONE device, each with a HIP stream, a calendar copy and an output workspace of its own: the shards of
     a rank go round-robin over them, so the kernels of neighbouring shards overlap (the HBM-heavy anomaly kernel of one band
-    runs beside the issue-bound threshold and mask kernels of another; measured on the 100-yr field: 155.5 -> 144 ms with two).
+    runs beside the latency-bound threshold kernel of another; measured on the 100-yr field, round 3: 141.0 ms with one stream,
+    129.5-133.5 with two, 128.8-129.8 with three).
     ``shard_step`` takes an ``EngineSet`` wherever it takes a single engine; results are those of one engine, bit for bit
     (``tests/test_gpu_sharding.py``)."""
 
@@ -148,10 +149,10 @@ class EngineSet:
 
     def calendars(self, cal):
         """Device copies of a calendar plan, one per engine (uploaded once per plan)."""
-        key = id(cal)
-        if key not in self._dcals:
-            self._dcals = {key: [e.upload_calendar(cal) for e in self.engines]}
-        return self._dcals[key]
+        held = self._dcals.get("plan")
+        if held is None or held[0] is not cal:  # the plan object is kept alive with its copies: an id() alone can be reused
+            self._dcals = {"plan": (cal, [e.upload_calendar(cal) for e in self.engines])}
+        return self._dcals["plan"][1]
 
     def sync(self) -> None:
         for e in self.engines:
