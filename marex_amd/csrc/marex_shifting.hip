@@ -450,7 +450,7 @@ struct DmaRows<7> {  // S = 11 (26 rows staged as 28): rows 0-3, 4, 5, 6
 // position of their buckets.
 __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, const float* __restrict__ edges, int nb,
                                  int want_bins, int enable, int* __restrict__ info, int4* __restrict__ fplan, long T, long C,
-                                 int reg_S, int4* __restrict__ lplan, const int* __restrict__ doy_start, int wpb) {
+                                 int reg_S, int4* __restrict__ lplan, const int* __restrict__ doy_start, int wpb, int lean_bins) {
     __shared__ int s_edges_ok;
     const int t = threadIdx.x;
     int eok = 1;
@@ -512,6 +512,21 @@ __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, 
         // wpb = waves (chunks of 4 dayofyears) per workgroup of the lean kernel: 4 or 8
         const int H = reg_S / 2, NPAIR = (reg_S + 3) / 2, NROWS = wpb * ((reg_S + 4 * wpb - 1 + wpb - 1) / wpb);
         const int d0 = chunk * 4, blk16 = (chunk / wpb) * wpb * 4;
+        // bin-matrix output (lean_bins): a regular year's 4 bin rows are row0 + {0, D1, D2, D3} with the SAME D every year (the
+        // distance of the dayofyears' buckets); D comes from the first year whose 4 dayofyears all have a bin row and travels in
+        // the padding record of "year -1"
+        int D1 = 0, D2 = 0, D3 = 0;
+        if (lean_bins && d0 + 3 < NDOY)
+            for (int y2 = 0; y2 < n_cal; ++y2) {
+                const int z0 = year_plan[(size_t)y2 * NDOY + d0].z, z1 = year_plan[(size_t)y2 * NDOY + d0 + 1].z;
+                const int z2 = year_plan[(size_t)y2 * NDOY + d0 + 2].z, z3 = year_plan[(size_t)y2 * NDOY + d0 + 3].z;
+                if (z0 >= 0 && z1 >= 0 && z2 >= 0 && z3 >= 0) {
+                    D1 = z1 - z0;
+                    D2 = z2 - z0;
+                    D3 = z3 - z0;
+                    break;
+                }
+            }
         for (int yy = sub - 1; yy <= n_cal; yy += CLASSIFY_SPLIT) {
             int flags = 0, tbv = -1, pos = 0;
             long long xoff = 0, ooff = 0;
@@ -533,15 +548,22 @@ __global__ void k_shift_classify(const int4* __restrict__ year_plan, int n_cal, 
                 if (e[0].y >= 0) {
                     flags |= 2;  // LR_OUT
                     ooff = (long long)e[0].y * C * 4;
-                    pos = e[0].z - doy_start[d0];
-                    reg = reg && pos >= 0 && pos < TAIL_MAX_BUCKET;
-                    for (int i = 1; i < 4; ++i) reg = reg && e[i].y == e[0].y + i && e[i].z - doy_start[d0 + i] == pos;
+                    if (lean_bins) {
+                        pos = e[0].z;  // the first bin row itself
+                        reg = reg && pos >= 0 && e[1].z == pos + D1 && e[2].z == pos + D2 && e[3].z == pos + D3;
+                        for (int i = 1; i < 4; ++i) reg = reg && e[i].y == e[0].y + i;
+                    } else {
+                        pos = e[0].z - doy_start[d0];
+                        reg = reg && pos >= 0 && pos < TAIL_MAX_BUCKET;
+                        for (int i = 1; i < 4; ++i) reg = reg && e[i].y == e[0].y + i && e[i].z - doy_start[d0 + i] == pos;
+                    }
                 }
                 if (reg) flags |= 1;  // LR_REG
             }
             int4* r = lplan + ((size_t)(yy + 1) * LEAN_CHUNKS + chunk) * 2;
             r[0] = make_int4(flags, tbv, (int)(unsigned)(xoff & 0xFFFFFFFFll), (int)(unsigned)((unsigned long long)xoff >> 32));
             r[1] = make_int4((int)(unsigned)(ooff & 0xFFFFFFFFll), (int)(unsigned)((unsigned long long)ooff >> 32), pos, 0);
+            if (yy < 0 && lean_bins) r[1] = make_int4(0, D1, D2, D3);
             // the waves of the last workgroup that have no dayofyears (chunks 92..95 with 8 waves) only help staging: the
             // workgroup's part of the record, nothing of a chunk
             if (chunk + 4 >= 92 && chunk + 4 < (92 + wpb - 1) / wpb * wpb) {
@@ -1056,11 +1078,13 @@ __device__ __forceinline__ void unroll_steps(F&& f) {
 #define LR_OUT 2         // an output year
 #define LR_STAGE_NEXT 4  // next year's rows of the workgroup can be staged (the block lies inside the series)
 
-template <int W, int S, int NWV>  // NWV waves = 4 NWV dayofyears per workgroup: 4 (36 rows staged for 16) or 8 (52 for 32)
+// BINS: the 2-byte bin matrix of k_shift_fast<W, false> (short series: the band threshold kernel reads it) instead of the key lists
+template <int W, int S, int NWV, bool BINS>  // NWV waves = 4 NWV dayofyears per workgroup: 4 (36 rows staged for 16) or 8 (52 for 32)
 __global__ void __launch_bounds__(64 * NWV, 16 / NWV)  // sixteen waves per CU: at most 128 VGPRs
 k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__ fplan, const int4* __restrict__ lplan, int n_cal,
              const int* __restrict__ info, const float* __restrict__ edges, int nb, float* __restrict__ out,
-             unsigned char* __restrict__ mask, int* __restrict__ invalid_count, int ncg, int nblk, TailOut tails) {
+             unsigned char* __restrict__ mask, int* __restrict__ invalid_count, int ncg, int nblk, TailOut tails,
+             unsigned short* __restrict__ bins, long T_out) {
     int cg, bc;
     if (!xcd_swizzle(blockIdx.x, ncg, nblk, cg, bc)) return;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1074,7 +1098,7 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
     // the stage has NWV RPW rows
     constexpr int NROWS = NWV * RPW;
     __shared__ float stage[NROWS * 64];
-    __shared__ unsigned newkeys[NWV][2][SHIFT_LIST][64];  // [wave][pair of dayofyears][year slot][lane]
+    __shared__ unsigned newkeys[BINS ? 1 : NWV][2][BINS ? 1 : SHIFT_LIST][64];  // [wave][pair of dayofyears][year slot][lane]
     const bool mine = chunk < 92 && info[chunk] != 0;  // wave-uniform; the other waves only help staging
     const int d0 = mine ? chunk * 4 : 0;
     const int c = cg * 64 + lane;
@@ -1092,6 +1116,10 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
     const float c0 = (1.0f - e_first * inv_width) - 0.0078125f;
     const float qnan = nan_f();
     if (chunk == 0 && mine && mask && active) mask[c] = finite_f(x[c]) ? 1 : 0;
+    // bin matrix (BINS): lane part of the element index relative to the wave's first 16-cell block, as in k_shift_fast
+    const unsigned bin_lane = (((cidx >> 4) - (unsigned)(cg * 4)) * (unsigned)T_out * 16u + (cidx & 15u)) * 2u;  // bytes
+    const rsrc_t rbins = make_rsrc(BINS ? bins + (size_t)(cg * 4) * (size_t)T_out * 16 : nullptr);
+    int bD1 = 0, bD2 = 0, bD3 = 0;  // bin rows of dayofyears 1..3 relative to dayofyear 0 (regular years)
 
     // lane offsets of the 4-row instruction (lane 16 r + s: row r, cells 4 s .. 4 s + 3 of the group; a segment beyond C -- C is a
     // multiple of 4 here -- reads the last four cells instead: those lanes are masked wherever they store)
@@ -1108,6 +1136,12 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
     const int4* lr_next = lplan + (size_t)chunk * 2;  // "year -1"
     {
         const int4 pre = lr_next[0];
+        if (BINS) {
+            const int4 preB = lr_next[1];
+            bD1 = preB.y;
+            bD2 = preB.z;
+            bD3 = preB.w;
+        }
         if (pre.x & LR_STAGE_NEXT) {
             dma_rows(pre.z, pre.w);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1328,9 +1362,11 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
         if (dead) {
             n_invalid += 4;
             if (cA.x & LR_OUT) {
-                newkeys[wave][0][t_slot][lane] = 0u;
-                newkeys[wave][1][t_slot][lane] = 0u;
-                ++t_slot;
+                if (!BINS) {
+                    newkeys[wave][0][t_slot][lane] = 0u;
+                    newkeys[wave][1][t_slot][lane] = 0u;
+                    ++t_slot;
+                }
                 const unsigned long long ooff = ((unsigned long long)(unsigned)cB.y << 32) | (unsigned)cB.x;
                 const rsrc_t ro = make_rsrc(reinterpret_cast<char*>(out) + ooff);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1339,6 +1375,12 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
                     stb_f32(ro, voff, rowb, __builtin_canonicalizef(xcA.y));
                     stb_f32(ro, voff, 2 * rowb, __builtin_canonicalizef(xcB.x));
                     stb_f32(ro, voff, 3 * rowb, __builtin_canonicalizef(xcB.y));
+                    if (BINS) {  // NaN: the overflow bin
+                        stb_u16(rbins, bin_lane, cB.z * 32, nb);
+                        stb_u16(rbins, bin_lane, (cB.z + bD1) * 32, nb);
+                        stb_u16(rbins, bin_lane, (cB.z + bD2) * 32, nb);
+                        stb_u16(rbins, bin_lane, (cB.z + bD3) * 32, nb);
+                    }
                 }
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1351,6 +1393,25 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
             int k0, k1, k2, k3;
             digit2(aA, k0, k1);
             digit2(aB, k2, k3);
+            if constexpr (BINS) {
+                k0 = (aA.x == aA.x) ? k0 : nb;  // NaN: the overflow bin (a value beyond the table got it from the digitize)
+                k1 = (aA.y == aA.y) ? k1 : nb;
+                k2 = (aB.x == aB.x) ? k2 : nb;
+                k3 = (aB.y == aB.y) ? k3 : nb;
+                const unsigned long long ooffb = ((unsigned long long)(unsigned)cB.y << 32) | (unsigned)cB.x;
+                const rsrc_t rob = make_rsrc(reinterpret_cast<char*>(out) + ooffb);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (active) {
+                    stb_f32(rob, voff, 0, aA.x);
+                    stb_f32(rob, voff, rowb, aA.y);
+                    stb_f32(rob, voff, 2 * rowb, aB.x);
+                    stb_f32(rob, voff, 3 * rowb, aB.y);
+                    stb_u16(rbins, bin_lane, cB.z * 32, k0);
+                    stb_u16(rbins, bin_lane, (cB.z + bD1) * 32, k1);
+                    stb_u16(rbins, bin_lane, (cB.z + bD2) * 32, k2);
+                    stb_u16(rbins, bin_lane, (cB.z + bD3) * 32, k3);
+                }
+            } else {
             const unsigned pos = (unsigned)cB.z, kb = 128u + pos;  // ((k + 1) << 7) | pos = (k << 7) + (128 + pos)
             const bool v0 = aA.x < e_last, v1 = aA.y < e_last, v2 = aB.x < e_last, v3 = aB.y < e_last;  // countable: a number below the last edge
             const unsigned q0 = v0 ? ((unsigned)k0 << TAIL_POS_BITS) + kb : 0u, q1 = v1 ? ((unsigned)k1 << TAIL_POS_BITS) + kb : 0u;
@@ -1378,6 +1439,7 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
                 stb_f32(ro, voff, rowb, aA.y);
                 stb_f32(ro, voff, 2 * rowb, aB.x);
                 stb_f32(ro, voff, 3 * rowb, aB.y);
+            }
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1430,6 +1492,14 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
                 int k0, k1, k2, k3;
                 digit2(aA, k0, k1);
                 digit2(aB, k2, k3);
+                if constexpr (BINS) {
+                    if (active) {
+                        stb_u16(rbins, bin_lane, pA.w * 32, (aA.x == aA.x) ? k0 : nb);
+                        if (has1) stb_u16(rbins, bin_lane, pB.x * 32, (aA.y == aA.y) ? k1 : nb);
+                        if (has2) stb_u16(rbins, bin_lane, pB.y * 32, (aB.x == aB.x) ? k2 : nb);
+                        if (has3) stb_u16(rbins, bin_lane, pB.z * 32, (aB.y == aB.y) ? k3 : nb);
+                    }
+                } else {
                 const float l1 = has1 ? e_last : -__builtin_inff(), l2 = has2 ? e_last : -__builtin_inff(),
                             l3 = has3 ? e_last : -__builtin_inff();  // uniform
                 const bool v0 = aA.x < e_last, v1 = aA.y < l1, v2 = aB.x < l2, v3 = aB.y < l3;
@@ -1453,6 +1523,7 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
                     t_ovfB = s2 | (s3 << 16);
                 }
                 ++t_slot;
+                }
             }
         } else {
             mid(cA);  // nothing to compute: the barrier, the staging and the record prefetch all the same
@@ -1474,7 +1545,7 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
             n_gen += mine ? 1 : 0;                                                                              \
         }                                                                                                       \
         asm volatile("s_barrier" ::: "memory"); /* every wave's DMA has landed: the stage holds next year's rows */ \
-        if (t_slot == SHIFT_LIST) tails_flush();                                                                \
+        if (!BINS && t_slot == SHIFT_LIST) tails_flush();                                                       \
     }
     for (int y = 0; y < n_cal; y += U) {
         MAREX_LEAN_YEAR(0, y)
@@ -1488,7 +1559,7 @@ k_shift_lean(const float* __restrict__ x, int T, int C, const int4* __restrict__
         }
     }
 #undef MAREX_LEAN_YEAR
-    if (mine) {
+    if (mine && !BINS) {
         if (t_slot > 0) tails_flush();
         while (t_list < tails.nper) tails_flush();
         if (active) {
@@ -1551,11 +1622,17 @@ template <int W, int S = 21>
 static void launch_shift_fast(marex_ctx* ctx, const ShiftArgs& a) {
     const int ncg = (int)((a.C + 63) / 64);
 #define MAREX_SF_ARGS dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (long)a.T, (long)a.C, a.fplan, a.n_cal, a.skip, a.write_clim, a.edges, a.nb, (long)a.T_out, a.out, a.bins, a.mask, a.invalid_count, ncg, 23, a.tails
-    if (a.tails.lists && a.lean) {
+    if (a.lean && (a.tails.lists || a.bins)) {
         if constexpr (S == 21 && (W == 15 || W == 5)) {
             // (NWV = 8 -- 52 rows staged for 32 dayofyears -- measured 11.2 ms against 10.0 per 100-yr band and is not instantiated)
-            hipLaunchKernelGGL((k_shift_lean<W, S, 4>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (int)a.T, (int)a.C, a.fplan,
-                                   a.lplan, a.n_cal, a.skip, a.edges, a.nb, a.out, a.mask, a.invalid_count, ncg, 23, a.tails);
+            if (a.tails.lists)
+                hipLaunchKernelGGL((k_shift_lean<W, S, 4, false>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (int)a.T, (int)a.C,
+                                   a.fplan, a.lplan, a.n_cal, a.skip, a.edges, a.nb, a.out, a.mask, a.invalid_count, ncg, 23, a.tails,
+                                   (unsigned short*)nullptr, (long)a.T_out);
+            else
+                hipLaunchKernelGGL((k_shift_lean<W, S, 4, true>), dim3(xcd_grid(ncg, 23)), dim3(256), 0, ctx->stream, a.x, (int)a.T, (int)a.C,
+                                   a.fplan, a.lplan, a.n_cal, a.skip, a.edges, a.nb, a.out, a.mask, a.invalid_count, ncg, 23, a.tails,
+                                   a.bins, (long)a.T_out);
         }
     } else if (a.tails.lists) {
         // LDS-DMA staging + L2 prefetch (option SHIFT_DMA=1; measured round 3 on a 100-yr band: 12.17 ms against 11.84 ms with
@@ -1622,7 +1699,9 @@ static int shifting_impl(marex_ctx* ctx, const char* who, const float* x, int64_
     LaunchTimer lt(ctx, MAREX_K_SHIFTING);  // one timed region: classify + fast kernel + general kernel
     if (fast_cfg) {
         // the lean kernel stages its rows by LDS-DMA: whole 16-byte segments of a row inside the field or beyond it (C % 4 == 0)
-        const bool lean = tails.lists && lean_instance(W, S) && ctx_opt(ctx, "SHIFT_LEAN", 1) != 0 && C >= 4 && C % 4 == 0 &&
+        // (the bin-matrix variant, option SHIFT_LEAN_BINS: short series whose thresholds come from the band kernel)
+        const bool lean_bins = !tails.lists && bins && !write_clim && ctx_opt(ctx, "SHIFT_LEAN_BINS", 1) != 0;
+        const bool lean = (tails.lists || lean_bins) && lean_instance(W, S) && ctx_opt(ctx, "SHIFT_LEAN", 1) != 0 && C >= 4 && C % 4 == 0 &&
                           T < (1ll << 31) - 64 && (unsigned long long)(S + 31 + 8 + 4) * (unsigned long long)C * 4ull < 0xFFFFFFFFull;
         const int lean_waves = 4;
         if (lean && ctx->shift_lplan_years < (size_t)n_cal_years) {
@@ -1637,7 +1716,8 @@ static int shifting_impl(marex_ctx* ctx, const char* who, const float* x, int64_
         }
         hipLaunchKernelGGL(k_shift_classify, dim3(1), dim3(1024), 0, ctx->stream, a.year_plan, n_cal_years, edges, nb,
                            (bins || tails.lists) ? 1 : 0, 1, ctx->shift_info, reinterpret_cast<int4*>(ctx->shift_plan), (long)T, (long)C,
-                           lean ? S : 0, lean ? reinterpret_cast<int4*>(ctx->shift_lplan) : nullptr, tails.doy_start, lean_waves);
+                           lean ? S : 0, lean ? reinterpret_cast<int4*>(ctx->shift_lplan) : nullptr, tails.doy_start, lean_waves,
+                           (lean && lean_bins) ? 1 : 0);
         a.lean_waves = lean_waves;
         a.lplan = reinterpret_cast<const int4*>(ctx->shift_lplan);
         a.lean = lean;

@@ -237,6 +237,9 @@ k_thresholds(const unsigned short* __restrict__ bins, long T_out, long C, int ny
 #ifndef TB_ROWWIN
 #define TB_ROWWIN 16  // levels a tile row reads at once in the row-pooled search
 #endif
+#ifndef TB_ROWBACK
+#define TB_ROWBACK 2  // how far below yesterday's level a lane wants its row window to start
+#endif
 #ifndef TB_BATCH
 #define TB_BATCH 16
 #endif
@@ -652,7 +655,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
                     const int khi = BW + 1;
                     int top = (khi - 1) & ~3;
                     top = top > 60 ? 60 : (top < 0 ? 0 : top);
-                    int start = ((hint >= 0 ? hint : ((1 + khi) >> 1)) - 2) & ~3;
+                    int start = ((hint >= 0 ? hint : ((1 + khi) >> 1)) - TB_ROWBACK) & ~3;  // the 16-level row window starts further below yesterday's level than an 8-level one
                     start = start < 0 ? 0 : (start > top ? top : start);
                     constexpr int RW = TB_ROWWIN;  // levels the row reads at once (a multiple of 4)
                     int u = row_min(want ? start : 0x7fffffff);

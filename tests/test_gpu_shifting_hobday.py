@@ -243,3 +243,36 @@ def test_cell_groups_that_are_all_nan_for_some_years(hot, path):
     check_all(*r)
     r = run_case(hot, "1986-01-01", 34 * 365 + 8, 4, 80, 15, 21, 11, 5, mutate=mutate, path=path)
     check_all(*r)
+
+
+@pytest.mark.parametrize("W,years,start,nx", [(5, 12, "2001-03-17", 52), (15, 33, "1990-07-01", 64), (5, 10, "2000-01-01", 80)])
+def test_lean_and_fast_anomaly_kernels_agree_on_the_bin_matrix(hot, W, years, start, nx):
+    """The bin-matrix variant of k_shift_lean (short series whose thresholds come from the band kernel) against k_shift_fast
+    (SHIFT_LEAN_BINS=0) on the same awkward fields, including whole cell groups of NaN: same anomalies, counts and bins."""
+    tm = calendar.daily_time_axis(start, years * 365 + years // 4)
+    x = synth.synth_field(synth.make_tables(tm, 4, nx))
+    ocean = np.flatnonzero(np.isfinite(x[0]))
+    x[400:430, ocean[0]] = np.nan
+    x[: 3 * 365, ocean[1]] = np.nan
+    x[:, ocean[2]] += np.float32(40.0) * (np.arange(x.shape[0]) % 7 == 0)
+    x[1234, ocean[3]] = np.inf
+    x[2345, ocean[4]] = -np.inf
+    x[: 2 * 365 + 50, 64:128] = np.nan  # a whole cell group that starts late
+    x[:, 128:192] = np.nan              # land
+    cal = calendar.build_calendar(tm, window_year_baseline=W)
+    dcal = hot.upload_calendar(cal)
+    bt = binning.hobday_bins()
+    xd = torch.from_numpy(x).to(hot.device)
+    res = {}
+    for lean in (1, 0):
+        with hot.ctx.options(SHIFT_LEAN_BINS=lean):
+            a = hot.shifting_baseline(xd, dcal, W, 21, bt)
+            hot.sync()
+        res[lean] = {k: a[k].cpu().numpy().copy() for k in ("out", "mask", "invalid_count", "bins")}
+    for k in res[1]:
+        assert np.array_equal(res[1][k], res[0][k], equal_nan=res[1][k].dtype.kind == "f"), k
+    exp, mask = orc.shifting_baseline_anomaly(x, cal, W, 21)
+    assert np.array_equal(res[1]["out"], exp, equal_nan=True) and np.array_equal(res[1]["mask"].astype(bool), mask)
+    bins_exp = orc.digitize_bins(exp, bt.edges)[cal.doy_rows]
+    bins_got = HotPath.bins_to_rows(torch.from_numpy(res[1]["bins"]).to(hot.device), x.shape[1]).cpu().numpy().view(np.uint16)
+    assert np.array_equal(bins_got, bins_exp)
