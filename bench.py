@@ -9,7 +9,8 @@
 A "step" = one pass of validation + shifting-baseline anomaly + day-of-year thresholds + extreme mask
 over one synthetic field that is already resident in HBM.  Metric (BASELINE.json): Mcells*timesteps/s
 (input timesteps), whole job.  Default workload `cfg3` = the configuration the metric is quoted on: the
-100-yr daily 1440x720 field (151 GB), resident as 8 overlapped latitude bands; N ranks take 8/N bands each
+100-yr daily 1440x720 field (151 GB), resident as overlapped latitude bands (6 of 120 rows where the rank count
+divides 6, else 8 of 90: whole rows of 30-row threshold tiles either way); N ranks take 1/N of the bands each
 (strong scaling, N in {1,2,4,8}).  `--workload cfg2` = the 10-yr field, one 720-row band per rank (weak
 scaling).  Bands are ingested with ws//2 overlap rows per interior side (marex_amd/dist.py); the collectives
 are a broadcast of the host-built tables (calendar, bin edges / centres, detrend model) from rank 0 before the
@@ -47,14 +48,14 @@ WORKLOADS = {
     # overlapped latitude bands; every rank streams its 8/N bands through one reusable output workspace
     # (314 GB of input + output do not fit 288 GB at once).  Strong scaling over N in {1,2,4,8}.
     "cfg3": dict(start="1925-01-01", T=36500, ny=720, nx=1440, W=15, S=21, wd=11, ws=5, pct=95.0, bands=8,
-                 name="100yr-daily x 1440x720 (0.25deg) in 8 resident latitude bands, shifting_baseline(W=15,S=21)+hobday_extreme p95"),
+                 name="100yr-daily x 1440x720 (0.25deg) in {bands} resident latitude bands, shifting_baseline(W=15,S=21)+hobday_extreme p95"),
     # BASELINE.json configs[3]: 30-yr daily x 2e6-cell unstructured mesh on 4 GPUs = 500 000 cells per GPU (weak scaling),
     # shifting_baseline + hobday_extreme p95, no spatial pooling (detect.py:1361-1385)
     "cfg4": dict(start="1995-01-01", T=10957, ny=0, nx=500_000, W=15, S=21, wd=11, ws=1, pct=95.0,
                  name="30yr-daily x 500000 cells per GPU of an unstructured mesh (2e6 cells on 4 GPUs), shifting_baseline(W=15,S=21)+hobday_extreme p95, no pooling"),
     # BASELINE.json configs[4]: the 100-yr field with detrend_fixed_baseline (orders 1, 2) + hobday_extreme p90
     "cfg5": dict(start="1925-01-01", T=36500, ny=720, nx=1440, W=None, S=21, wd=11, ws=5, pct=90.0, bands=8, detrend_orders=(1, 2),
-                 name="100yr-daily x 1440x720 (0.25deg) in 8 resident latitude bands, detrend_fixed_baseline(orders 1,2)+hobday_extreme p90"),
+                 name="100yr-daily x 1440x720 (0.25deg) in {bands} resident latitude bands, detrend_fixed_baseline(orders 1,2)+hobday_extreme p90"),
 }
 
 
@@ -298,6 +299,21 @@ def main():
     T, nx, W = wl["T"], wl["nx"], wl["W"]
     halo = wl["ws"] // 2
     nbands = wl.get("bands", 0)
+    if nbands:
+        # The band count is the rank's own tiling of ITS HBM, not part of the workload: the 720 rows are 24 rows of 30-row
+        # threshold tiles, so whole tile rows allow 6, 8, 12 or 24 bands.  Fewer, taller bands carry fewer overlap rows
+        # (124 / 120 instead of 94 / 90) and split evenly over two streams: 6 bands where the rank count divides 6 and two
+        # band workspaces fit beside the rank's share of the field (measured at N = 1: 126.5 ms against 128.8-130.3 with 8
+        # bands on three streams, 131.8 with 12), else 8.  MAREX_BENCH_BANDS overrides (experiments).
+        if "MAREX_BENCH_BANDS" in os.environ:
+            nbands = int(os.environ["MAREX_BENCH_BANDS"])
+        else:
+            nbands = next((nb for nb in (6, 8, 12, 24) if nb % world == 0), 0)
+            if nbands == 6:
+                cells6 = (wl["ny"] // 6 + 2 * halo) * nx
+                need = (6 // world) * cells6 * 4 * T + 2 * 1.1 * (cells6 * (5 * T + 12 * 366) + cells6 * 2 * 366 * 16 * (T // 365 // 15 + 1))
+                if need > torch.cuda.mem_get_info(local_rank)[0] and 8 % world == 0:
+                    nbands = 8
     if nbands:  # fixed global grid cut into `nbands` bands, strong scaling: rank r takes bands r, r+world, ...
         if nbands % world:
             raise SystemExit(f"--workload {args.workload} needs a GPU count that divides {nbands}")
@@ -314,7 +330,8 @@ def main():
 
     # default: three engines when their workspaces fit beside the resident input (measured on the 100-yr field, round 3: 141.0 ms with one
     # stream, 129.5-133.5 with two, 128.8-129.8 with three), else two; one for a single band and for the one-GPU rehearsal of several ranks
-    nstream = args.streams if args.streams > 0 else (1 if (len(shards) == 1 or one_gpu) else 3)
+    # (an even number of bands goes over two streams: same speed as three with 8 bands, faster with 6)
+    nstream = args.streams if args.streams > 0 else (1 if (len(shards) == 1 or one_gpu) else (2 if len(shards) % 2 == 0 else 3))
     nstream = max(1, min(nstream, len(shards)))
     if args.streams <= 0 and nstream == 3:
         cells = max(sh.cells_in for sh in shards)
@@ -463,7 +480,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": wl["name"],
+                "workload": wl["name"].replace("{bands}", str(nbands)),
                 "per_gpu_grid": [sum(sh.own1 - sh.own0 for sh in shards), nx] if ny_total else [sum(sh.cells_own for sh in shards)],
                 "global_grid": [ny_total, nx] if ny_total else [nx * world],
                 "bands_per_gpu": len(shards),
