@@ -309,6 +309,8 @@ def main():
             nbands = int(os.environ["MAREX_BENCH_BANDS"])
         else:
             nbands = next((nb for nb in (6, 8, 12, 24) if nb % world == 0), 0)
+            if not nbands:
+                raise SystemExit(f"--workload {args.workload} needs a GPU count that divides 24 (whole rows of threshold tiles per band)")
             if nbands == 6:
                 cells6 = (wl["ny"] // 6 + 2 * halo) * nx
                 need = (6 // world) * cells6 * 4 * T + 2 * 1.1 * (cells6 * (5 * T + 12 * 366) + cells6 * 2 * 366 * 16 * (T // 365 // 15 + 1))
