@@ -206,6 +206,10 @@ extern "C" int marex_mask_ge_doy_f32(marex_ctx* ctx, const float* anom, const fl
             const unsigned ncb4 = (unsigned)((nc / 4 + 255) / 256);
             unsigned chunks = (4096 + ncb4 - 1) / ncb4;
             chunks = chunks < MASK_DOY_CHUNKS ? MASK_DOY_CHUNKS : (chunks > 61 ? 61 : chunks);
+            {
+                const int forced = ctx_opt(ctx, "MASK_CHUNKS", 0);  // dayofyear chunks of the grid (experiments)
+                if (forced >= 1 && forced <= 366) chunks = (unsigned)forced;
+            }
             dim3 grid(ncb4, chunks);
             hipLaunchKernelGGL(k_mask_ge<4>, grid, dim3(256), 0, ctx->stream, anom, thr_doy_major, doy_start, doy_rows,
                                (long)C, (long)c0, (long)c1, extreme, n_true);

@@ -1395,8 +1395,14 @@ extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, co
     {
         LaunchTimer lt(ctx, MAREX_K_MASK);
         const unsigned ncb = (unsigned)(((c1 - c0) / 4 + 255) / 256);
-        unsigned chunks = (4096 + ncb - 1) / ncb;
+        // about 16 000 workgroups (measured on 100-yr bands of 90 / 120 rows: 33 / 25 chunks 2.25 / 2.90 ms, 61 chunks 2.12 / 2.79 ms,
+        // 122 chunks 2.11 ms; the whole pass 125.7 -> 124.3 ms)
+        unsigned chunks = (16384 + ncb - 1) / ncb;
         chunks = chunks < MASK_DOY_CHUNKS ? MASK_DOY_CHUNKS : (chunks > 61 ? 61 : chunks);
+        {
+            const int forced = ctx_opt(ctx, "MASK_CHUNKS", 0);  // dayofyear chunks of the grid (experiments)
+            if (forced >= 1 && forced <= 366) chunks = (unsigned)forced;
+        }
         unsigned long long* dbg = ctx_debug_counters(ctx);
         const uint4* tl = reinterpret_cast<const uint4*>(lists);
         // byte offset of every kept row of the MASK array (one byte per cell) in dayofyear order
