@@ -329,6 +329,7 @@ __device__ __forceinline__ void tl_bump_chunk(const uint4& ch, int n, int B0, in
 #define TT_BW 64       // bins per band
 #define TT_MARGIN 6    // re-centre when the day's quantile bins come this close to a band edge
 #define TT_STEP 56     // band shift when answering stragglers (8 bins of overlap)
+static_assert(TT_STEP <= TT_BW - 8, "straggler passes must overlap: a quantile bin between two tried bands would never be found");
 #define TT_NPF 2       // chunk-0s of a bucket prefetched across the barrier (the other lists are loaded at use)
 
 template <int NPERT>
