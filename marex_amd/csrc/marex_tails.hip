@@ -770,6 +770,10 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned* __restrict__ aux, i
 #endif
             const int lo = s_lo[par], hi = s_hi[par];
             if (!lo && !hi) break;
+            if (pass > 2 * (nb / TT_STEP) + 8) {  // cannot happen while the bands of the passes overlap (static_assert above): a
+                if (!resolved) thr[(size_t)d * C + cell] = nan_f();  // wave must always reach the end of the walk
+                break;
+            }
             // stragglers: a band further down (first) or further up than anything tried for this day
             if (lo) {
                 B0 = clamp_base(tried_lo - TT_STEP);
