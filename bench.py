@@ -213,6 +213,12 @@ class _null:
         return False
 
 
+def band_count(world: int) -> int:
+    """Latitude bands of the 100-yr field for `world` ranks: the 720 rows are 24 rows of 30-row threshold tiles, so whole tile
+    rows allow 6, 8, 12 or 24 bands; the smallest count the rank count divides (6 at N = 1, 2, 3, 6; 8 at N = 4, 8), 0 if none."""
+    return next((nb for nb in (6, 8, 12, 24) if nb % world == 0), 0)
+
+
 def spawn_ranks(n: int, argv) -> int:
     """`python bench.py --gpus N` as a plain command: this process -- which has made no GPU call -- starts N ranks of itself
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set them), lets rank 0 print the JSON line on
@@ -308,7 +314,7 @@ def main():
         if "MAREX_BENCH_BANDS" in os.environ:
             nbands = int(os.environ["MAREX_BENCH_BANDS"])
         else:
-            nbands = next((nb for nb in (6, 8, 12, 24) if nb % world == 0), 0)
+            nbands = band_count(world)
             if not nbands:
                 raise SystemExit(f"--workload {args.workload} needs a GPU count that divides 24 (whole rows of threshold tiles per band)")
             if nbands == 6:
