@@ -282,7 +282,7 @@ def main():
     import torch.distributed as dist
 
     from marex_amd import binning, calendar, synth
-    from marex_amd.dist import EngineSet, allreduce_step, broadcast_tables, plan_shards, shard_step
+    from marex_amd.dist import SUMMARY_KEYS, EngineSet, allreduce_step, broadcast_tables, plan_shards, shard_step
     from marex_amd.engine import HotPath
 
     rank = int(os.environ.get("RANK", "0"))
@@ -419,9 +419,11 @@ def main():
     kern = {k: v for k, v in kern.items() if v[1]}
     timers.timing_enable(False)
     path = r.get("path", "bins")
-    summary = dict(zip(["n_ocean", "invalid_total", "invalid_cells", "n_extreme", "thr_too_low", "thr_too_high"],
-                       [int(v) for v in local.tolist()]))
+    summary = dict(zip(SUMMARY_KEYS, [int(v) for v in local.tolist()]))
     summary["max_invalid"] = int(mx.item())
+    failures = []  # a line whose results are in doubt is not a benchmark line: printed with "failed", exit code 1
+    if summary.get("thr_unresolved"):
+        failures.append(f"threshold kernel left {summary['thr_unresolved']} outputs unresolved")
 
     if rank == 0:
         C_own_total = ny_total * nx if ny_total else nx * world
@@ -455,6 +457,9 @@ def main():
             except Exception as e:  # noqa: BLE001
                 serial = {"error": f"{type(e).__name__}: {e}"[:300]}
                 torch.cuda.empty_cache()
+        if serial and "n_extreme" in serial and serial["n_extreme"] != summary["n_extreme"]:
+            failures.append(f"n_extreme of the timed region ({summary['n_extreme']}) differs from the single-stream pass of the same "
+                            f"step ({serial['n_extreme']})")
         per_launch = serial["kernel_ms"] if serial and serial.get("kernel_ms") else None
         dom = max(per_launch, key=per_launch.get) if per_launch else max(kern, key=lambda k: kern[k][0])
         # HBM bytes of the dominant kernel from the committed PMC passes of this same command (profiles/)
@@ -465,7 +470,7 @@ def main():
                   "thresholds": "k_thr_tails" if path == "tails" else "k_thr_band",
                   "mask": "k_mask_tails" if path == "tails" else "k_mask_ge"}
         kname = knames[dom]
-        for rnd in ("r03", "r02"):
+        for rnd in ("r04", "r03", "r02"):
             tfile = os.path.join(ROOT, "profiles", f"{rnd}_{args.workload}_traffic.json")
             if world == 1 and traffic is None and os.path.exists(tfile):
                 for name, rec in json.load(open(tfile)).get("kernels", {}).items():
@@ -492,6 +497,7 @@ def main():
                 "per_gpu_grid": [sum(sh.own1 - sh.own0 for sh in shards), nx] if ny_total else [sum(sh.cells_own for sh in shards)],
                 "global_grid": [ny_total, nx] if ny_total else [nx * world],
                 "bands_per_gpu": len(shards),
+                "bands_total": nbands or world,  # the tiling changes with the rank count (6 bands at N = 1, 2; 8 at N = 4, 8): same field, same results
                 "streams_per_gpu": nstream,
                 "timesteps_in": T,
                 "timesteps_out": T_out,
@@ -500,7 +506,18 @@ def main():
                 "summary": summary,
                 "histogram_representation": path,
             },
+            # the figure north_star's ">= 40 % of HBM roofline" speaks about: SURVEY 8(d) bytes of the whole path / step time
+            "pipeline_roofline": {
+                "what": "whole path: algorithmic bytes of a step (SURVEY.md 8d) / ms_per_step -- the north-star fraction",
+                "algorithmic_bytes_per_step_per_gpu": b_alg_rank,
+                "achieved": b_alg_rank / (dt / args.steps) / 1e9,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": b_alg_rank / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+            },
+            # the dominant KERNEL alone (its own algorithmic bytes / its own launch duration): kernel quality, not the path
             "roofline": {
+                "what": "dominant kernel only: its algorithmic bytes per launch / its average launch duration",
                 "bound": "hbm",
                 "kernel": kname,
                 "achieved": achieved,
@@ -512,13 +529,6 @@ def main():
                 "algorithmic_bytes_per_launch": per_kernel_alg[dom],
                 "timing": ("HIP events on the launch stream, single-stream pass of the same step inside this run (extra.single_stream)"
                            if per_launch else "HIP events on the launch stream over the timed region"),
-            },
-            "pipeline_roofline": {
-                "algorithmic_bytes_per_step_per_gpu": b_alg_rank,
-                "achieved": b_alg_rank / (dt / args.steps) / 1e9,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": b_alg_rank / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             },
             "kernel_ms": avg_ms,
         }
@@ -546,10 +556,14 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(wl, args.seed)
             except Exception as e:  # noqa: BLE001  (a host without room for the worker pool still gets its GPU line)
                 out["cpu_baseline"] = {"value": None, "unit": "Mcells*timesteps/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"[:300]}
+        if failures:
+            out["failed"] = failures
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if failures:
+        raise SystemExit("bench.py: " + "; ".join(failures))
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MAREX_ABI_VERSION 1
+#define MAREX_ABI_VERSION 2
 #define MAREX_NDOY 366
 
 typedef struct marex_ctx marex_ctx;
@@ -39,7 +39,10 @@ typedef struct marex_thr_stats {
     uint32_t max_key;   /* order-preserving key of the largest threshold (0 if none)                      */
     uint32_t n_too_low; /* thresholds < lower_bound (they are clamped to it)                              */
     uint32_t n_too_high;/* thresholds > upper_bound                                                       */
-} marex_thr_stats;
+    uint32_t n_unresolved; /* outputs a threshold kernel gave up on (written as NaN): an internal error, the host
+                              side raises ProcessingError when it is not 0 (never observed; marex_tails.hip, straggler passes) */
+    uint32_t reserved[3];
+} marex_thr_stats;  /* 32 bytes; callers zero it except min_key = 0xFFFFFFFF */
 
 /* kernel ids for marex_timing_get */
 enum {

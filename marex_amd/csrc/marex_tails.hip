@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 4 : (NT == 512 ? 2 : 1))
 k_thr_tails(const uint4* __restrict__ lists, const unsigned* __restrict__ aux, int NPER, int nch, const float* __restrict__ anom,
             long C, int ny, int nx, int row0, int row1, int tiles_x, int Dd, const float* __restrict__ centres, int nb, double q,
             int wd, float lower_bound, float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats,
-            unsigned long long* __restrict__ dbg) {
+            unsigned long long* __restrict__ dbg, int pass_limit) {
     constexpr int TR = TR_;
     constexpr int NCELL = TR * TC;
     constexpr int NPF = NPERT < TT_NPF ? NPERT : TT_NPF;
@@ -770,8 +770,11 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned* __restrict__ aux, i
 #endif
             const int lo = s_lo[par], hi = s_hi[par];
             if (!lo && !hi) break;
-            if (pass > 2 * (nb / TT_STEP) + 8) {  // cannot happen while the bands of the passes overlap (static_assert above): a
-                if (!resolved) thr[(size_t)d * C + cell] = nan_f();  // wave must always reach the end of the walk
+            if (pass >= pass_limit) {  // cannot happen while the bands of the passes overlap (static_assert above), but a wave must
+                if (!resolved) {       // always reach the end of the walk: the output is counted as unresolved (the host raises) and NaN
+                    thr[(size_t)d * C + cell] = nan_f();
+                    atomicAdd(&stats->n_unresolved, 1u);
+                }
                 break;
             }
             // stragglers: a band further down (first) or further up than anything tried for this day
@@ -1124,7 +1127,10 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((NDOY + Dd - 1) / Dd));
     unsigned long long* dbg = ctx_debug_counters(ctx);
     const uint4* tl = reinterpret_cast<const uint4*>(lists);
-#define MAREX_TT_ARGS tl, aux, NPER, nch, anom, (long)C, ny, nx, row0, row1, tiles_x, Dd, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats, dbg
+    // straggler passes per day before the kernel gives up on an output (never reached: the tried bands overlap, so at most
+    // nb / TT_STEP + 1 passes in either direction find any bin; option THR_PASS_LIMIT exists for the test of the error path)
+    const int pass_limit = ctx_opt(ctx, "THR_PASS_LIMIT", 2 * (nb / TT_STEP) + 9);
+#define MAREX_TT_ARGS tl, aux, NPER, nch, anom, (long)C, ny, nx, row0, row1, tiles_x, Dd, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats, dbg, pass_limit
 #define MAREX_TT_LAUNCH(PP, TCC, NTT, ...)                                                                                           \
     do {                                                                                                                             \
         if (NPER <= 1)                                                                                                               \
@@ -1179,10 +1185,13 @@ k_mask_tails(const uint4* __restrict__ lists, const unsigned* __restrict__ aux, 
              unsigned long long* __restrict__ dbg) {
     const int nchunk = (int)gridDim.y;
     const int dA = (int)blockIdx.y * NDOY / nchunk, dB = ((int)blockIdx.y + 1) * NDOY / nchunk;
-    const long c = c0 + ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    // lanes are laid over the cells from the multiple of 256 below c0: a wave's row segment is then 256 bytes at a 256-byte
+    // offset of the row (with two overlap rows of 1440 cells c0 = 2880 = 11.25 x 256, and every wave store straddled three
+    // 128-byte lines: the 1.21 x write amplification of the 100-yr bands, round 3)
+    const long c = (c0 & ~255L) + ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     unsigned cnt_true = 0;
     unsigned long long n_slow = 0;
-    if (c < c1) {
+    if (c >= c0 && c < c1) {
         const float inv_width = (float)(nb - 1) / (edges[nb] - edges[1]);
         for (int d = dA; d < dB; ++d) {
             const int r0 = doy_start[d], nd = doy_start[d + 1] - r0;
@@ -1399,7 +1408,7 @@ extern "C" int marex_mask_ge_doy_tails_f32(marex_ctx* ctx, const void* lists, co
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     {
         LaunchTimer lt(ctx, MAREX_K_MASK);
-        const unsigned ncb = (unsigned)(((c1 - c0) / 4 + 255) / 256);
+        const unsigned ncb = (unsigned)(((c1 - (c0 & ~255L)) / 4 + 255) / 256);
         // about 16 000 workgroups (measured on 100-yr bands of 90 / 120 rows: 33 / 25 chunks 2.25 / 2.90 ms, 61 chunks 2.12 / 2.79 ms,
         // 122 chunks 2.11 ms; the whole pass 125.7 -> 124.3 ms)
         unsigned chunks = (16384 + ncb - 1) / ncb;

@@ -113,7 +113,8 @@ def allreduce_summary(local: Dict[str, int], device=None) -> Dict[str, int]:
 # --------------------------------------------------------------------------------------
 # one pass of the hot path over a rank's shards + the scalar collectives (bench.py and the tests share this code)
 # --------------------------------------------------------------------------------------
-SUMMARY_KEYS = ("n_ocean", "invalid_total", "invalid_cells", "n_extreme", "thr_too_low", "thr_too_high")
+#: thr_unresolved: outputs the list threshold kernel gave up on (marex_thr_stats.n_unresolved) -- must be 0, callers raise otherwise
+SUMMARY_KEYS = ("n_ocean", "invalid_total", "invalid_cells", "n_extreme", "thr_too_low", "thr_too_high", "thr_unresolved")
 
 
 class EngineSet:
@@ -178,7 +179,7 @@ class EngineSet:
 
 
 def _one_shard(hot, sh, x, dcal, *, W, S, bins, q, wd, ws, nx, workspace, detrend):
-    """The four stages of one shard on one engine; returns (result dict, int64[6] partial summary, int64[1] max invalid)."""
+    """The four stages of one shard on one engine; returns (result dict, int64[7] partial summary, int64[1] max invalid)."""
     import torch
 
     own = sh.own_cell_slice()
@@ -193,7 +194,7 @@ def _one_shard(hot, sh, x, dcal, *, W, S, bins, q, wd, ws, nx, workspace, detren
         r = {"dat_anomaly": f["out"], "mask": f["mask"], "invalid_count": f["invalid_count"], "thr_doy_major": h["thr_doy_major"],
              "stats_dev": h["stats_dev"], "extreme_events": h["extreme"], "n_true": h["n_true"], "path": h["path"]}
     vs = hot.validation_summary(r["mask"], r["invalid_count"], (own.start, own.stop), workspace)  # a3 verdict
-    part = torch.cat([vs[0:3], r["n_true"].to(torch.int64).reshape(1), r["stats_dev"][2:4].to(torch.int64)])
+    part = torch.cat([vs[0:3], r["n_true"].to(torch.int64).reshape(1), r["stats_dev"][2:5].to(torch.int64)])
     return r, part, vs[3:4].clone()
 
 
@@ -204,13 +205,13 @@ def shard_step(hot, shards, xs, dcal, *, W: int = 15, S: int = 21, bins, q: floa
     ``detrend_fixed_baseline`` (detect.py:2400-2462).  ``hot``: one engine (shards one after the other on the current stream)
     or an :class:`EngineSet` (shards round-robin over its engines and streams; ``dcal`` may then be the host ``CalendarPlan``
     and ``workspace`` is ignored: every engine writes into its own).  Returns ``(result of the last shard, local, mx)``:
-    ``local`` int64[6] in ``SUMMARY_KEYS`` order and ``mx`` int64[1] (largest per-cell invalid count) on the device, not yet
+    ``local`` int64[7] in ``SUMMARY_KEYS`` order and ``mx`` int64[1] (largest per-cell invalid count) on the device, not yet
     reduced over ranks and valid on the CALLER's current stream."""
     import torch
 
     kw = dict(W=W, S=S, bins=bins, q=q, wd=wd, ws=ws, nx=nx, detrend=detrend)
     if not isinstance(hot, EngineSet):
-        local = torch.zeros(6, dtype=torch.int64, device=hot.device)
+        local = torch.zeros(len(SUMMARY_KEYS), dtype=torch.int64, device=hot.device)
         mx = torch.zeros(1, dtype=torch.int64, device=hot.device)
         r = None
         for sh, x in zip(shards, xs):
@@ -236,7 +237,7 @@ def shard_step(hot, shards, xs, dcal, *, W: int = 15, S: int = 21, bins, q: floa
             part.record_stream(main)  # allocated on the engine's stream, read on the caller's
             m.record_stream(main)
             parts[k].append((part, m))
-    local = torch.zeros(6, dtype=torch.int64, device=es.device)
+    local = torch.zeros(len(SUMMARY_KEYS), dtype=torch.int64, device=es.device)
     mx = torch.zeros(1, dtype=torch.int64, device=es.device)
     for k, e in enumerate(es.engines):
         if not parts[k]:

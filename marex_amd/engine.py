@@ -211,7 +211,7 @@ class HotPath:
         T_out, Cn = binsb.shape[1], first_anom.shape[-1]
         row0, row1 = rows if rows is not None else (0, max(ny, 1))
         thr = self._buf(wsp, "thr_doy_major", (N_DOY, Cn), torch.float32, self.device)
-        stats = self._buf(wsp, "thr_stats", (4,), torch.int32, self.device)
+        stats = self._buf(wsp, "thr_stats", (8,), torch.int32, self.device)  # marex_thr_stats: 8 x uint32
         stats.zero_()
         stats[0:1].fill_(-1)  # min_key = 0xFFFFFFFF (a fill kernel: `stats[0] = -1` would be a blocking host-to-device copy)
         centres = self.bin_tables(bins)[1]
@@ -227,6 +227,12 @@ class HotPath:
     def decode_thr_stats(stats_dev: torch.Tensor) -> Dict[str, float]:
         s = stats_dev.cpu().numpy().view(np.uint32)
         kmin, kmax = int(s[0]), int(s[1])
+        if len(s) > 4 and int(s[4]):  # the straggler-pass limit of the list threshold kernel tripped (marex_tails.hip): never a result
+            raise ProcessingError(
+                f"threshold kernel left {int(s[4])} outputs unresolved (written as NaN)",
+                details="internal error of the day-of-year threshold stage: the band search ran out of passes",
+                suggestions=["force the bin-matrix kernels (engine.hobday_path = 'bins') and report the input"],
+            )
         return {
             "min": _key_to_float(kmin) if kmin != 0xFFFFFFFF else float("nan"),
             "max": _key_to_float(kmax) if kmax != 0 else float("nan"),
@@ -318,7 +324,7 @@ class HotPath:
         T_out, Cn = anom.shape
         row0, row1 = rows if rows is not None else (0, max(ny, 1))
         thr = self._buf(wsp, "thr_doy_major", (N_DOY, Cn), torch.float32, self.device)
-        stats = self._buf(wsp, "thr_stats", (4,), torch.int32, self.device)
+        stats = self._buf(wsp, "thr_stats", (8,), torch.int32, self.device)  # marex_thr_stats: 8 x uint32
         stats.zero_()
         stats[0:1].fill_(-1)
         centres = self.bin_tables(bins)[1]
@@ -794,7 +800,7 @@ class HotPath:
         gb = global_bins(bins.precision, bins.max_anomaly)
         edges = self._dev(gb.edges.astype(np.float64))
         centres = self._dev(gb.centres.astype(np.float64))
-        stats = torch.zeros((4,), dtype=torch.int32, device=self.device)
+        stats = torch.zeros((8,), dtype=torch.int32, device=self.device)
         minmax = torch.tensor([float("inf"), float("-inf")], dtype=torch.float64, device=self.device)
         rc = self.lib.marex_global_threshold_f32(
             self.ctx.handle, anom.data_ptr(), T_out, Cn, q, 0, edges.data_ptr(), centres.data_ptr(), gb.nb,

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.marex_abi_version() == 1
+    assert lib.marex_abi_version() == 2
 
 
 def test_bad_context_is_an_error_code_not_a_crash():

@@ -58,7 +58,7 @@ class OracleEngine:
             "thr_doy_major": torch.from_numpy(np.ascontiguousarray(r["thresholds"].T)),
             "extreme_events": torch.from_numpy(r["extreme_events"].astype(np.uint8)),
             "n_true": torch.tensor([int(r["extreme_events"][:, own].sum())], dtype=torch.int64),
-            "stats_dev": torch.tensor([0, 0, low, 0], dtype=torch.int32),
+            "stats_dev": torch.tensor([0, 0, low, 0, 0, 0, 0, 0], dtype=torch.int32),
         }
 
     def validation_summary(self, mask, invalid, cells, wsp=None):

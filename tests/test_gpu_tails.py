@@ -151,6 +151,30 @@ def test_seasonal_and_patchy_thresholds_move_the_band(hot, tile):
     _thr_case(hot, anom, cal, bt, 90.0, 5, 3, 40, 36, opts={"THR_TILE": tile})
 
 
+def test_straggler_pass_limit_is_an_error_not_a_result(hot):
+    """The list threshold kernel gives up on an output after `pass_limit` straggler passes (never reached in the product:
+    tests/test_tail_constants.py).  With the limit forced to 0 on a field that NEEDS extra passes, the unresolved outputs are
+    counted in marex_thr_stats.n_unresolved and the host raises instead of handing NaN thresholds on."""
+    from marex_amd.exceptions import ProcessingError
+
+    tm, cal, _, rng = make_anomalies(30, 40 * 36, seed=5)
+    field = rng.normal(0, 1, (cal.T_out, 40, 36)).astype(np.float32) * np.float32(0.4)
+    field[:, :, 18:] *= np.float32(2.5)                                          # two bands of thresholds inside one tile
+    anom = np.ascontiguousarray(field.reshape(cal.T_out, -1))
+    bt = binning.hobday_bins()
+    dcal = hot.upload_calendar(cal)
+    ad = torch.from_numpy(anom).to(hot.device)
+    tl = hot.tail_extract(ad, dcal, bt)
+    with hot.ctx.options(THR_PASS_LIMIT=0, THR_TILE=32):
+        t = hot.hobday_thresholds_tails(tl, ad, dcal, bt, 0.95, 11, 5, 40, 36)
+        hot.sync()
+    with pytest.raises(ProcessingError, match="unresolved"):
+        HotPath.decode_thr_stats(t["stats_dev"])
+    t = hot.hobday_thresholds_tails(tl, ad, dcal, bt, 0.95, 11, 5, 40, 36)     # the product limit: resolved, no error
+    hot.sync()
+    assert "n_too_low" in HotPath.decode_thr_stats(t["stats_dev"])
+
+
 def test_owned_rows_and_unstructured(hot):
     tm, cal, anom, rng = make_anomalies(20, 23 * 31, seed=8)
     bt = binning.hobday_bins()
