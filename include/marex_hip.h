@@ -62,6 +62,30 @@ enum {
 };
 
 int marex_abi_version(void);
+
+/* Sizes of the caller-owned device buffers of one spatial block (the caller owns every data buffer, the library
+ * only its handle and scratch).  bytes[MAREX_WS_COUNT] in the order of the enum; MAREX_WS_TOTAL = what one pass of
+ * shifting_baseline / fixed_baseline + hobday_extreme needs beside the input (anomalies, mask bytes, thresholds in both layouts,
+ * key lists + aux OR the bin matrix, per-cell mask and counts).  Returns -1 for a null pointer or an impossible shape. */
+typedef struct marex_workspace_cfg {
+    int64_t T;        /* input timesteps                                                              */
+    int64_t T_out;    /* kept timesteps (T minus the first window_year_baseline years for shifting_baseline) */
+    int64_t C;        /* cells of the block, overlap rows included                                      */
+    int max_bucket;   /* rows of the largest dayofyear bucket                                           */
+    int list_rows;    /* rows per key list: 15 (lists emitted by the anomaly kernel), 32 (extraction kernel), 0: bin-matrix path */
+} marex_workspace_cfg;
+enum {
+    MAREX_WS_ANOMALY = 0,   /* float [T_out][C]                         */
+    MAREX_WS_EXTREME = 1,   /* uint8 [T_out][C]                         */
+    MAREX_WS_THRESHOLDS = 2,/* float [366][C], dayofyear-major AND cell-major: two buffers of this size */
+    MAREX_WS_LISTS = 3,     /* key lists [366][NPER][nch][C] x 16 bytes (0 on the bin-matrix path)     */
+    MAREX_WS_AUX = 4,       /* uint32 [366][C] (0 on the bin-matrix path)                              */
+    MAREX_WS_BINS = 5,      /* uint16 [ceil(C/16)][T_out][16] (0 on the list path)                     */
+    MAREX_WS_PER_CELL = 6,  /* uint8 mask [C] + int32 invalid_count [C]                                */
+    MAREX_WS_TOTAL = 7,
+    MAREX_WS_COUNT = 8
+};
+int marex_workspace_bytes(const marex_workspace_cfg* cfg, size_t* bytes);
 /* A context owns small device scratch buffers that its launches share: use one context per (device, host thread,
  * stream); launches through one context are stream-ordered and must not overlap on different streams. */
 int marex_create(int device, marex_ctx** out);
@@ -260,6 +284,20 @@ int marex_detrend_fixed_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, 
                                      const int32_t* doy_start,
                                      const int32_t* doy_rows, const uint8_t* use_row, int max_bucket, float* out,
                                      uint8_t* mask, int32_t* invalid_count);
+/* The two fixed-baseline stages above (detect.py:2299-2397, 2400-2462) that also leave the sorted key lists of their own output
+ * -- exactly what marex_tail_extract_f32(out, list_rows = 32) would write (TAILS, below): `lists` [366][NPER][4][C] x 16 bytes with
+ * NPER = marex_tail_lists(max_bucket, 32), `aux` [366][C]; the bucket is in registers when its anomalies are formed, so the
+ * threshold stage needs no extraction pass (a read of the whole anomaly field: 13 ms per 100-yr band, round 3).  `edges[0..nb]`
+ * as for marex_tail_extract_f32; nb <= 511, max_bucket <= 128 (-4 otherwise: run the plain entry point + marex_tail_extract_f32). */
+int marex_fixed_baseline_tails_f32(marex_ctx* ctx, const float* x, const float* sub, int max_bucket, int64_t T, int64_t C,
+                                   const int32_t* doy_start, const int32_t* doy_rows, const uint8_t* use_row,
+                                   const float* edges, int nb, float* out, uint8_t* mask, int32_t* invalid_count,
+                                   void* lists, uint32_t* aux);
+int marex_detrend_fixed_baseline_tails_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
+                                           const double* model_t, const double* model_sorted, int n_coef,
+                                           int force_zero_mean, const int32_t* doy_start, const int32_t* doy_rows,
+                                           const uint8_t* use_row, int max_bucket, const float* edges, int nb, float* out,
+                                           uint8_t* mask, int32_t* invalid_count, void* lists, uint32_t* aux);
 
 /*
  * Exact Hobday percentile (detect.py:1921-1956): thr[d, c] = np.nanpercentile(anom[doy in window(d), c], p),

@@ -25,6 +25,7 @@ _f64 = C.c_double
 #: name -> (restype, argtypes); must list every function declared in include/marex_hip.h
 PROTOTYPES = {
     "marex_abi_version": (_i32, []),
+    "marex_workspace_bytes": (_i32, [_p, _p]),
     "marex_create": (_i32, [_i32, C.POINTER(_p)]),
     "marex_destroy": (_i32, [_p]),
     "marex_last_error": (C.c_char_p, [_p]),
@@ -49,6 +50,9 @@ PROTOTYPES = {
     "marex_detrend_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
     "marex_detrend_deferred_mean_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p]),
     "marex_detrend_fixed_baseline_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p]),
+    "marex_fixed_baseline_tails_f32": (_i32, [_p, _p, _p, _i32, _i64, _i64, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
+    "marex_detrend_fixed_baseline_tails_f32": (
+        _i32, [_p, _p, _i64, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p]),
     "marex_fixed_baseline_sub_f32": (_i32, [_p, _p, _p, _i32, _i64, _i64, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     "marex_hobday_exact_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i32, _f32, _f64, _i32, _p, _p]),
     "marex_global_threshold_f32": (_i32, [_p, _p, _i64, _i64, _f64, _i32, _p, _p, _i32, _f64, _f64, _p, _p, _p]),

@@ -1,5 +1,6 @@
 // marex_anomalies.hip -- fixed baseline, digitize, detrend, std_normalise
 #include "marex_common.hip.h"
+#include "marex_tails.hip.h"
 
 // ------------------------------------------------------------------------------------------------
 // K_F: fixed-baseline anomaly (detect.py:2299-2397).  Work item = (256 cells, one dayofyear): the
@@ -60,12 +61,32 @@ k_fixed_baseline(const float* __restrict__ x, long T, long C, const int* __restr
 // NC > 0: x is the RAW field and the sample is its detrend residual, x - fl32(sum_k model_t[t][k] * coef[k][c]) (the arithmetic of
 // k_detrend_resid, recomputed here so that the residual field is never written or read: detrend_fixed_baseline in 3 reads and
 // 1 write of the field).
-template <int NMAX, int NC = 0>
+// TAILS: the kernel also leaves the sorted key lists of its own output (marex_tails.hip.h, lists of 32 rows: what
+// k_tail_extract would make of `out`), so that the threshold and mask kernels need no extraction pass -- a read of the whole
+// anomaly field and 13 ms per 100-yr band of the detrend_fixed_baseline path (round 3).  A lane holds ONE bucket, so the packed
+// 16-bit sorting networks take two LISTS of that bucket per register (rows 64 P + u in the low halves, rows 64 P + 32 + u in the
+// high ones) instead of two dayofyears: 2 x 206 compare-exchanges for a 100-row bucket, hidden behind the kernel's memory time.
+template <int NMAX, int NC = 0, bool TAILS = false>
 __global__ void __launch_bounds__(256)
 k_fixed_baseline_reg(const float* __restrict__ x, long C, const int* __restrict__ doy_start, const int* __restrict__ doy_rows,
                      const unsigned char* __restrict__ use_row, float* __restrict__ out, unsigned char* __restrict__ mask,
                      int* __restrict__ invalid_count, const float* __restrict__ sub, const double* __restrict__ model_t = nullptr,
-                     const double* __restrict__ coef = nullptr) {
+                     const double* __restrict__ coef = nullptr, const float* __restrict__ edges = nullptr, int nb = 0,
+                     uint4* __restrict__ lists = nullptr, unsigned* __restrict__ aux = nullptr, int NPER_ALL = 0) {
+    extern __shared__ float e_lds[];  // TAILS: [nb + 1] edge table
+    bool lean = false;
+    float e_first = 0.f, e_delta = 0.f, e_last = 0.f, inv_width = 0.f, c0 = 0.f, nbm1f = 0.f;
+    if (TAILS) {
+        for (int i = threadIdx.x; i <= nb; i += 256) e_lds[i] = edges[i];
+        __syncthreads();
+        e_first = e_lds[1], e_delta = e_lds[2] - e_lds[1], e_last = e_lds[nb];
+        inv_width = (float)(nb - 1) / (e_last - e_first);
+        lean = edges_are_arange(e_lds, nb);  // the anomaly kernels' digitize (marex_tails.hip: k_tail_extract)
+        const double m = fabs((double)e_first) > fabs((double)e_last) ? fabs((double)e_first) : fabs((double)e_last);
+        lean = lean && e_delta > 0.f && ((double)nb + 2.0 * m / (double)e_delta) * (1.0 / 1048576.0) < 1.0 / 256.0;
+        c0 = (1.0f - e_first * inv_width) - 0.0078125f;
+        nbm1f = (float)(nb - 1);
+    }
     const int d = blockIdx.y;
     const long c_raw = (long)blockIdx.x * 256 + threadIdx.x;
     const bool active = c_raw < C;
@@ -129,10 +150,88 @@ k_fixed_baseline_reg(const float* __restrict__ x, long C, const int* __restrict_
         if (b < nrow) {
 #pragma unroll
             for (int u = 0; u < 16; ++u)
-                if (b + u < nrow && active) out[(size_t)doy_rows[r0 + b + u] * C + c] = v[b + u] - clim;
+                if (b + u < nrow) {
+                    v[b + u] = v[b + u] - clim;  // from here on the registers hold the anomalies (TAILS reads them again)
+                    if (active) out[(size_t)doy_rows[r0 + b + u] * C + c] = v[b + u];
+                }
         }
     }
     if (invalid_count && n_invalid && active) atomicAdd(&invalid_count[c], n_invalid);
+    if constexpr (TAILS) {
+        constexpr int NPAIRS = (NMAX + 63) / 64;  // pairs of 32-row lists
+        // NPER_ALL: lists per bucket of the buffer (ceil(max_bucket / 32)); lists beyond this bucket's rows are written empty
+        unsigned cnt = 0, ovf = 0;
+        auto key_of = [&](float a, int pos) -> unsigned {
+            int k;
+            if (lean) {
+                const float f = __builtin_fmaf(a, inv_width, c0);
+                const float t = __builtin_amdgcn_fmed3f(__builtin_floorf(f), 0.0f, nbm1f);
+                const float ehi = e_first + t * e_delta;
+                k = (int)t + (a >= ehi ? 1 : 0);
+                k = (a == a) ? k : nb;
+            } else {
+                k = digitize_bin(a, e_lds, nb, inv_width);
+            }
+            const bool ok = k < nb;
+            cnt += ok ? 1u : 0u;
+            return ok ? tail_key(k, pos) : 0u;
+        };
+        // one pair of lists (rows 64 P .. 64 P + 63) -- as a macro per P: a loop over P with this body is not unrolled by hipcc,
+        // and a runtime P indexes the register array v[] (which then lives in scratch memory: 528 bytes per lane)
+#define MAREX_FB_PAIR(P)                                                                                          \
+    if (2 * (P) < NPER_ALL) {                                                                                     \
+            unsigned pk[32]; \
+            float amax = -__builtin_inff(); \
+_Pragma("unroll") \
+            for (int u = 0; u < 32; ++u) { \
+                const int ra = 64 * P + u, rb = 64 * P + 32 + u; \
+                unsigned ka = 0u, kb = 0u; \
+                if (ra < NMAX && ra < nrow) { \
+                    ka = key_of(v[ra < NMAX ? ra : 0], ra); \
+                    amax = fmaxf(amax, v[ra < NMAX ? ra : 0]); \
+                } \
+                if (rb < NMAX && rb < nrow) { \
+                    kb = key_of(v[rb < NMAX ? rb : 0], rb); \
+                    amax = fmaxf(amax, v[rb < NMAX ? rb : 0]); \
+                } \
+                pk[u] = ka | (kb << 16); \
+            } \
+            if (__builtin_amdgcn_ballot_w64(amax >= e_last) != 0) { \
+_Pragma("unroll") \
+                for (int r = 64 * P; r < 64 * P + 64; ++r) \
+                    if (r < NMAX && r < nrow && v[r < NMAX ? r : 0] >= e_last) ovf = tail_ovf_add(ovf, (unsigned)r); \
+            } \
+            sort16_desc(reinterpret_cast<unsigned(&)[16]>(pk[0])); \
+            sort16_desc(reinterpret_cast<unsigned(&)[16]>(pk[16])); \
+_Pragma("unroll") \
+            for (int i = 0; i < 8; ++i) { \
+                const unsigned tmp = pk[16 + i]; \
+                pk[16 + i] = pk[31 - i]; \
+                pk[31 - i] = tmp; \
+            } \
+            bitonic_merge_desc<32>(pk); \
+            if (active) { \
+_Pragma("unroll") \
+                for (int j = 0; j < 4; ++j) { \
+                    uint4 w0, w1; \
+                    unsigned* a = reinterpret_cast<unsigned*>(&w0); \
+                    unsigned* b = reinterpret_cast<unsigned*>(&w1); \
+_Pragma("unroll") \
+                    for (int i = 0; i < 4; ++i) { \
+                        const unsigned xk = pk[8 * j + 2 * i], yk = pk[8 * j + 2 * i + 1]; \
+                        a[i] = (xk & 0xFFFFu) | (yk << 16); \
+                        b[i] = (xk >> 16) | (yk & 0xFFFF0000u); \
+                    } \
+                    if (2 * P < NPER_ALL) lists[(((size_t)d * NPER_ALL + 2 * P) * 4 + j) * C + c] = w0; \
+                    if (2 * P + 1 < NPER_ALL) lists[(((size_t)d * NPER_ALL + 2 * P + 1) * 4 + j) * C + c] = w1; \
+                } \
+            } \
+    }
+        MAREX_FB_PAIR(0)
+        if constexpr (NPAIRS > 1) { MAREX_FB_PAIR(1) }
+#undef MAREX_FB_PAIR
+        if (active) aux[(size_t)d * C + c] = tail_aux_word(cnt, ovf);
+    }
 }
 
 static int fixed_baseline_impl(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const int32_t* doy_start,
@@ -361,16 +460,31 @@ extern "C" int marex_detrend_deferred_mean_f32(marex_ctx* ctx, const float* x, i
 // detrend_fixed_baseline (detect.py:2400-2462) as one chain: fit (one read of x), residual mean (one read, nothing written),
 // then the climatology kernel recomputes every residual from x while it reads its dayofyear bucket (one read, one write).
 // Covers n_coef <= 5 and buckets <= 128 rows; -4 otherwise (callers then run the two stages separately).
-extern "C" int marex_detrend_fixed_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
-                                                const double* model_t, const double* model_sorted, int n_coef, int force_zero_mean,
-                                                const int32_t* doy_start,
-                                                const int32_t* doy_rows, const uint8_t* use_row, int max_bucket, float* out,
-                                                uint8_t* mask, int32_t* invalid_count) {
+static int tails32_check(marex_ctx* ctx, const char* who, const float* edges, int nb, void* lists, uint32_t* aux, int max_bucket,
+                        int64_t C, int& nper) {
+    if (!edges || !lists || !aux) return fail(ctx, -1, "%s: null pointer", who);
+    if (nb < 4 || nb > TAIL_MAX_NB || max_bucket < 1 || max_bucket > TAIL_MAX_BUCKET || C > (1 << 24))
+        return fail(ctx, -4, "%s: the key lists need nb <= %d, buckets of at most %d rows and C <= 2^24", who, TAIL_MAX_NB, TAIL_MAX_BUCKET);
+    if (((uintptr_t)lists & 15) != 0) return fail(ctx, -1, "%s: lists must be 16-byte aligned", who);
+    nper = (max_bucket + 31) / 32;
+    return 0;
+}
+
+static int detrend_fixed_baseline_impl(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
+                                       const double* model_t, const double* model_sorted, int n_coef, int force_zero_mean,
+                                       const int32_t* doy_start, const int32_t* doy_rows, const uint8_t* use_row, int max_bucket,
+                                       float* out, uint8_t* mask, int32_t* invalid_count, const float* edges, int nb, void* lists,
+                                       uint32_t* aux) {
     if (!ctx) return -1;
     if (!x || !pmodel || !model_t || !model_sorted || !doy_start || !doy_rows || !out || T <= 0 || C <= 0)
         return fail(ctx, -1, "marex_detrend_fixed_baseline_f32: null pointer or empty shape");
     if (n_coef < 1 || n_coef > 5 || max_bucket < 1 || max_bucket > 128)
         return fail(ctx, -4, "marex_detrend_fixed_baseline_f32: covers 1..5 coefficients and buckets of at most 128 rows");
+    int nper = 0;
+    if (lists) {
+        const int rc = tails32_check(ctx, "marex_detrend_fixed_baseline_tails_f32", edges, nb, lists, aux, max_bucket, C, nper);
+        if (rc) return rc;
+    }
     const double* coef = nullptr;
     const float* mean = nullptr;
     const int rc = detrend_impl(ctx, x, T, C, pmodel, model_t, n_coef, force_zero_mean, nullptr, mask, invalid_count, nullptr, true,
@@ -378,19 +492,71 @@ extern "C" int marex_detrend_fixed_baseline_f32(marex_ctx* ctx, const float* x, 
     if (rc != 0) return rc;
     const float* sub = force_zero_mean ? mean : nullptr;
     dim3 grid((unsigned)((C + 255) / 256), NDOY);
+    uint4* tl = reinterpret_cast<uint4*>(lists);
+    const size_t lds = lists ? (size_t)(nb + 1) * sizeof(float) : 0;
     {
         LaunchTimer lt(ctx, MAREX_K_FIXED);
+#define MAREX_DF_LAUNCH(NM, N, TL)                                                                                                \
+    hipLaunchKernelGGL((k_fixed_baseline_reg<NM, N, TL>), grid, dim3(256), lds, ctx->stream, x, (long)C, doy_start, doy_rows, use_row, \
+                       out, nullptr, nullptr, sub, model_sorted, coef, edges, nb, tl, aux, nper)
 #define MAREX_DF_CASE(N)                                                                                                          \
     case N:                                                                                                                       \
-        if (max_bucket <= 48)                                                                                                     \
-            hipLaunchKernelGGL((k_fixed_baseline_reg<48, N>), grid, dim3(256), 0, ctx->stream, x, (long)C, doy_start, doy_rows, use_row, \
-                               out, nullptr, nullptr, sub, model_sorted, coef);                                                  \
-        else                                                                                                                      \
-            hipLaunchKernelGGL((k_fixed_baseline_reg<128, N>), grid, dim3(256), 0, ctx->stream, x, (long)C, doy_start, doy_rows, use_row, \
-                               out, nullptr, nullptr, sub, model_sorted, coef);                                                  \
+        if (max_bucket <= 48) {                                                                                                   \
+            if (lists) MAREX_DF_LAUNCH(48, N, true); else MAREX_DF_LAUNCH(48, N, false);                                          \
+        } else {                                                                                                                  \
+            if (lists) MAREX_DF_LAUNCH(128, N, true); else MAREX_DF_LAUNCH(128, N, false);                                        \
+        }                                                                                                                         \
         break;
         switch (n_coef) { MAREX_DF_CASE(1) MAREX_DF_CASE(2) MAREX_DF_CASE(3) MAREX_DF_CASE(4) MAREX_DF_CASE(5) }
 #undef MAREX_DF_CASE
+#undef MAREX_DF_LAUNCH
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int marex_detrend_fixed_baseline_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
+                                                const double* model_t, const double* model_sorted, int n_coef, int force_zero_mean,
+                                                const int32_t* doy_start,
+                                                const int32_t* doy_rows, const uint8_t* use_row, int max_bucket, float* out,
+                                                uint8_t* mask, int32_t* invalid_count) {
+    return detrend_fixed_baseline_impl(ctx, x, T, C, pmodel, model_t, model_sorted, n_coef, force_zero_mean, doy_start, doy_rows,
+                                       use_row, max_bucket, out, mask, invalid_count, nullptr, 0, nullptr, nullptr);
+}
+
+// ... and the sorted key lists (32 rows per list) + aux words of the anomalies it writes: marex_tail_extract_f32(out) fused in
+extern "C" int marex_detrend_fixed_baseline_tails_f32(marex_ctx* ctx, const float* x, int64_t T, int64_t C, const double* pmodel,
+                                                      const double* model_t, const double* model_sorted, int n_coef,
+                                                      int force_zero_mean, const int32_t* doy_start, const int32_t* doy_rows,
+                                                      const uint8_t* use_row, int max_bucket, const float* edges, int nb, float* out,
+                                                      uint8_t* mask, int32_t* invalid_count, void* lists, uint32_t* aux) {
+    if (ctx && (!lists || !aux || !edges)) return fail(ctx, -1, "marex_detrend_fixed_baseline_tails_f32: null pointer");
+    return detrend_fixed_baseline_impl(ctx, x, T, C, pmodel, model_t, model_sorted, n_coef, force_zero_mean, doy_start, doy_rows,
+                                       use_row, max_bucket, out, mask, invalid_count, edges, nb, lists, aux);
+}
+
+// fixed_baseline (detect.py:2299-2397) with the key lists of its output: the register kernel (buckets of at most 128 rows)
+extern "C" int marex_fixed_baseline_tails_f32(marex_ctx* ctx, const float* x, const float* sub, int max_bucket, int64_t T, int64_t C,
+                                              const int32_t* doy_start, const int32_t* doy_rows, const uint8_t* use_row,
+                                              const float* edges, int nb, float* out, uint8_t* mask, int32_t* invalid_count,
+                                              void* lists, uint32_t* aux) {
+    if (!ctx) return -1;
+    if (!x || !doy_start || !doy_rows || !out || T <= 0 || C <= 0)
+        return fail(ctx, -1, "marex_fixed_baseline_tails_f32: null pointer or empty shape");
+    int nper = 0;
+    const int rc = tails32_check(ctx, "marex_fixed_baseline_tails_f32", edges, nb, lists, aux, max_bucket, C, nper);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((C + 255) / 256), NDOY);
+    const size_t lds = (size_t)(nb + 1) * sizeof(float);
+    {
+        LaunchTimer lt(ctx, MAREX_K_FIXED);
+        if (max_bucket <= 48)
+            hipLaunchKernelGGL((k_fixed_baseline_reg<48, 0, true>), grid, dim3(256), lds, ctx->stream, x, (long)C, doy_start, doy_rows,
+                               use_row, out, mask, invalid_count, sub, nullptr, nullptr, edges, nb, reinterpret_cast<uint4*>(lists), aux, nper);
+        else
+            hipLaunchKernelGGL((k_fixed_baseline_reg<128, 0, true>), grid, dim3(256), lds, ctx->stream, x, (long)C, doy_start, doy_rows,
+                               use_row, out, mask, invalid_count, sub, nullptr, nullptr, edges, nb, reinterpret_cast<uint4*>(lists), aux, nper);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;

@@ -3,6 +3,28 @@
 
 extern "C" int marex_abi_version(void) { return MAREX_ABI_VERSION; }
 
+extern "C" int marex_workspace_bytes(const marex_workspace_cfg* cfg, size_t* bytes) {
+    if (!cfg || !bytes || cfg->T <= 0 || cfg->T_out <= 0 || cfg->T_out > cfg->T || cfg->C <= 0) return -1;
+    const size_t C = (size_t)cfg->C, To = (size_t)cfg->T_out;
+    for (int i = 0; i < MAREX_WS_COUNT; ++i) bytes[i] = 0;
+    bytes[MAREX_WS_ANOMALY] = To * C * sizeof(float);
+    bytes[MAREX_WS_EXTREME] = To * C;
+    bytes[MAREX_WS_THRESHOLDS] = (size_t)MAREX_NDOY * C * sizeof(float);
+    if (cfg->list_rows > 0) {
+        const int nper = marex_tail_lists(cfg->max_bucket, cfg->list_rows);
+        if (nper < 1) return -1;
+        const size_t nch = cfg->list_rows <= 16 ? 2 : 4;
+        bytes[MAREX_WS_LISTS] = (size_t)MAREX_NDOY * (size_t)nper * nch * C * 16;
+        bytes[MAREX_WS_AUX] = (size_t)MAREX_NDOY * C * sizeof(uint32_t);
+    } else {
+        bytes[MAREX_WS_BINS] = ((C + 15) / 16) * To * 16 * sizeof(uint16_t);
+    }
+    bytes[MAREX_WS_PER_CELL] = C * (sizeof(uint8_t) + sizeof(int32_t));
+    bytes[MAREX_WS_TOTAL] = bytes[MAREX_WS_ANOMALY] + bytes[MAREX_WS_EXTREME] + 2 * bytes[MAREX_WS_THRESHOLDS] + bytes[MAREX_WS_LISTS] +
+                            bytes[MAREX_WS_AUX] + bytes[MAREX_WS_BINS] + bytes[MAREX_WS_PER_CELL];
+    return 0;
+}
+
 extern "C" int marex_create(int device, marex_ctx** out) {
     if (!out) return -1;
     int n = 0;

@@ -15,7 +15,7 @@ behind every spatial chunk:
 Differences from the eager call, by construction: ``_validate_data_values`` (detect.py:205-279) speaks about the whole field,
 so its verdict is reduced over the blocks by :func:`validation_summary` (a lazy scalar task the caller may compute first:
 ``check_valid=True`` does so before returning, as the reference validates eagerly, detect.py:583); the threshold-range
-warnings are emitted per block.
+warnings (detect.py:2711-2730) are reduced the same way and emitted ONCE for the field, when its thresholds are computed.
 
 Needs ``dask`` (and works on ``xarray.DataArray`` as well as on the stand-in ``marex_amd.DataArray`` wrapping a Dask array).
 Neither package exists in the build image: the task function :func:`run_block` -- everything except the graph wiring -- is
@@ -25,11 +25,12 @@ plain NumPy in / NumPy out and is tested on the GPU without Dask (tests/test_gpu
 
 from __future__ import annotations
 
+import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .detect import _infer_dims_coords, _raise_if_invalid, _validate_extreme_options, preprocess_data
+from .detect import _infer_dims_coords, _raise_if_invalid, _validate_extreme_options, preprocess_data, warn_threshold_stats
 from .dist import Shard, plan_shards
 from .exceptions import DependencyError, create_data_validation_error
 from .xr_compat import DataArray, Dataset, coord_values
@@ -48,19 +49,33 @@ def plan_spatial_blocks(ny: int, nx: int, halo: int, block_rows: Optional[int] =
     return plan_shards(0, nx, max(1, -(-nx // max(cells, 1))), 0)
 
 
+#: one block at a time per device: a device's engine (context, stream binding, scratch that grows with the block, cached tables)
+#: is shared by every task Dask's threaded scheduler hands to that card, and blocks i and i + len(devices) land on the same one
+_DEVICE_LOCKS: Dict[int, threading.Lock] = {}
+_DEVICE_LOCKS_GUARD = threading.Lock()
+
+
+def _device_lock(device: int) -> threading.Lock:
+    with _DEVICE_LOCKS_GUARD:
+        return _DEVICE_LOCKS.setdefault(int(device), threading.Lock())
+
+
 def run_block(x_block: np.ndarray, time: np.ndarray, shard: Shard, gridded: bool, dims: Sequence[str], coords: Dict[str, np.ndarray],
               kwargs: dict, device: int = 0) -> Dict[str, object]:
     """One spatial block on the device.  ``x_block``: ``[T, rows_in, nx]`` / ``[T, cells_in]`` (overlap rows included), returns
-    the OWNED part of every output variable as NumPy arrays plus the block's validation counts (``"_validation"``) and the
-    kept time axis (``"_time"``)."""
+    the OWNED part of every output variable as NumPy arrays plus the block's validation counts (``"_validation"``), its
+    threshold-range statistics (``"_thr_stats"``), the Dataset attrs and the kept time axis (``"_time"``).  Calls for the same
+    device are serialised (worker threads of a Dask scheduler may run them concurrently); different devices run side by side."""
     x_block = np.asarray(x_block)
     da = DataArray(x_block, dims=tuple(dims), coords={**coords, dims[0]: time})
     if gridded:
         r0, r1 = shard.own0 - shard.in0, shard.own1 - shard.in0
     else:
         r0, r1 = 0, shard.cells_own  # meshes carry no overlap
-    ds = preprocess_data(da, device=device, _validation="return", _own_rows=(r0, r1), **kwargs)
-    out: Dict[str, object] = {"_validation": dict(ds.attrs["_validation"]), "_attrs": {k: v for k, v in ds.attrs.items() if k != "_validation"}}
+    with _device_lock(device):
+        ds = preprocess_data(da, device=device, _validation="return", _own_rows=(r0, r1), _defer_warnings=True, **kwargs)
+    out: Dict[str, object] = {"_validation": dict(ds.attrs["_validation"]), "_thr_stats": list(ds.attrs["_thr_stats"]),
+                              "_attrs": {k: v for k, v in ds.attrs.items() if k not in ("_validation", "_thr_stats")}}
     for name in ds.data_vars:
         v = ds[name]
         a = np.asarray(v.values)
@@ -96,7 +111,7 @@ def preprocess_data_lazy(da, *, block_rows: Optional[int] = None, block_cells: O
     """``preprocess_data`` as a lazy Dask graph over spatial blocks with ``time: -1`` (module docstring).  ``da`` must be
     Dask-backed (the reference's own requirement, detect.py:558-568); keyword arguments are those of
     :func:`marex_amd.preprocess_data`.  Returns a Dataset whose variables are Dask arrays, chunked
-    ``{time: dask_chunks["time"] (default 25), space: -1}``; ``ds.attrs["validation"]`` is the lazy whole-field verdict
+    ``{time: dask_chunks["time"] (default 25), space: -1}``; ``ds.encoding["marex_validation"]`` is the lazy whole-field verdict
     (:func:`validation_summary`), raised as the reference's ``DataValidationError`` when computed through
     :func:`raise_if_invalid` -- ``check_valid=True`` does that before returning."""
     try:
@@ -179,14 +194,28 @@ def preprocess_data_lazy(da, *, block_rows: Optional[int] = None, block_cells: O
 
     doy = np.arange(1, 367)
     ds = Dataset()
+    max_anomaly = float(kw.get("max_anomaly", 5.0))
+
+    def _warn_once(stats_lists):
+        # ONE pair of threshold-range warnings for the field (detect.py:2711-2730), when its thresholds are computed
+        warn_threshold_stats([st for lst in stats_lists for st in lst], 2 if want_stn else 1, max_anomaly)
+        return True
+
+    warned = dask.delayed(_warn_once)([dask.delayed(lambda r: r["_thr_stats"])(t) for t in tasks])
     for name, dt in names.items():
         kind = layout[name]
         axis = {"t": 1, "s": 0, "sd": 0, "ds": 1}[kind]
-        parts = [dsa.from_delayed(dask.delayed(lambda r, n=name: r[n])(t), shape=shape_of(kind, sh), dtype=dt) for t, sh in zip(tasks, shards)]
+        if name == "thresholds":  # every block of the thresholds hangs on the field-wide warning task (which needs all blocks anyway)
+            parts = [dsa.from_delayed(dask.delayed(lambda r, _w, n=name: r[n])(t, warned), shape=shape_of(kind, sh), dtype=dt)
+                     for t, sh in zip(tasks, shards)]
+        else:
+            parts = [dsa.from_delayed(dask.delayed(lambda r, n=name: r[n])(t), shape=shape_of(kind, sh), dtype=dt) for t, sh in zip(tasks, shards)]
         arr = dsa.concatenate(parts, axis=axis) if len(parts) > 1 else parts[0]
         vdims = {"t": (tdim, *sdims), "s": tuple(sdims), "sd": (*sdims, "dayofyear"), "ds": ("dayofyear", *sdims)}[kind]
         # final rechunk (detect.py:785-792): space whole, time (and dayofyear) in chunks of dask_chunks["time"]
-        tch = int((dask_chunks or {}).get(tdim, (dask_chunks or {}).get("time", 25)))
+        # detect.py:787: dask_chunks.get(<time dim>, dask_chunks.get("time", 10)) with the signature's default {"time": 25}
+        dch = {"time": 25} if dask_chunks is None else dict(dask_chunks)
+        tch = int(dch.get(tdim, dch.get("time", 10)))
         chunks = {i: (tch if d in (tdim, "dayofyear") else -1) for i, d in enumerate(vdims)}
         arr = arr.rechunk(chunks)
         vcoords = {}
@@ -199,10 +228,14 @@ def preprocess_data_lazy(da, *, block_rows: Optional[int] = None, block_cells: O
                 vcoords[cname] = val if cd == (cname,) else (cd, val)
         ds[name] = DataArray(arr, dims=vdims, coords=vcoords)
     verdict = dask.delayed(_reduce_validation)([dask.delayed(lambda r: r["_validation"])(t) for t in tasks])
-    ds.attrs["validation"] = verdict
-    ds.attrs["_field_shape"] = (int(T), int(ny * nx if gridded else nx))
-    ds.attrs.update({"method_anomaly": kw.get("method_anomaly", "shifting_baseline"), "method_extreme": me,
-                     "threshold_percentile": kw.get("threshold_percentile", 95)})
+    # attrs: those of the eager Dataset (detect.py:731-783) -- they follow from the options alone, so they are taken from the
+    # same function without touching data; everything in them serialises (zarr / netCDF).  The lazy verdict and the field's
+    # shape travel in `encoding`, which no writer stores.
+    from .detect import dataset_attrs
+
+    ds.attrs.update(dataset_attrs(**{k: v for k, v in kw.items() if k not in ("dimensions", "coordinates")}))
+    ds.encoding["marex_validation"] = verdict
+    ds.encoding["marex_field_shape"] = (int(T), int(ny * nx if gridded else nx))
     if check_valid:
         raise_if_invalid(ds)
     return ds
@@ -210,10 +243,10 @@ def preprocess_data_lazy(da, *, block_rows: Optional[int] = None, block_cells: O
 
 def validation_summary(ds) -> Dict[str, int]:
     """The whole-field numbers of ``_validate_data_values`` (computes the blocks' anomaly stage)."""
-    v = ds.attrs["validation"]
+    v = ds.encoding["marex_validation"]
     return v.compute() if hasattr(v, "compute") else dict(v)
 
 
 def raise_if_invalid(ds) -> None:
     """Raise the reference's ``DataValidationError`` texts (detect.py:224-279) from the reduced counts."""
-    _raise_if_invalid(_ShapeOnly(ds.attrs["_field_shape"]), validation_summary(ds))
+    _raise_if_invalid(_ShapeOnly(ds.encoding["marex_field_shape"]), validation_summary(ds))

@@ -21,7 +21,7 @@ from typing import Dict, List, Literal, Optional, Tuple
 import numpy as np
 
 from . import binning, calendar
-from .exceptions import ConfigurationError, DataValidationError, create_data_validation_error
+from .exceptions import ConfigurationError, DataValidationError, ProcessingError, create_data_validation_error
 from .xr_compat import DataArray, Dataset, coord_values, to_numpy
 
 logger = logging.getLogger("marex_amd")
@@ -466,6 +466,13 @@ def _anomaly_core(eng, field: _Field, method_anomaly, window_year_baseline, smoo
         if callable(want_bins):
             tails_bins = want_bins(dcal, "tails")  # bin table when the anomaly kernel should emit the sorted key lists itself
             want_bins = want_bins(dcal)
+        from .engine import _note_path, shifting_kernel_family
+
+        fam = shifting_kernel_family(int(window_year_baseline), int(smooth_days_baseline), int(x.shape[1]), tails_bins is not None)
+        if fam != "lean":
+            _note_path(f"shifting_baseline: window_year_baseline={window_year_baseline}, smooth_days_baseline={smooth_days_baseline}, "
+                       f"{x.shape[1]} cells take the '{fam}' anomaly kernel (tuned path: smooth_days_baseline=21, "
+                       "window_year_baseline in (5, 15), cells a multiple of 4; same results)")
         if tails_bins is not None:
             r = eng.shifting_baseline_tails(x, dcal, int(window_year_baseline), int(smooth_days_baseline), tails_bins)
         else:
@@ -474,10 +481,12 @@ def _anomaly_core(eng, field: _Field, method_anomaly, window_year_baseline, smoo
                 "cal": cal, "dcal": dcal}
     cal = calendar.build_calendar(field.time)
     dcal = eng.upload_calendar(cal)
+    # bin table when the threshold stage will work from sorted key lists: the fixed-baseline kernels then emit them themselves
+    tails_bins = want_bins(dcal, "tails_fixed") if callable(want_bins) else None
     want_bins = want_bins(dcal) if callable(want_bins) else want_bins
     if method_anomaly == "fixed_baseline":
         _check_reference_period_values(reference_period, cal.year)
-        r = eng.fixed_baseline(x, dcal, reference_period, want_bins, count_invalid=True)
+        r = eng.fixed_baseline(x, dcal, reference_period, want_bins, count_invalid=True, tails_bins=tails_bins)
     elif method_anomaly in ("detrend_harmonic", "detrend_fixed_baseline"):
         _check_detrend_orders(detrend_orders)
         if 1 not in detrend_orders and len(detrend_orders) > 1:
@@ -487,7 +496,7 @@ def _anomaly_core(eng, field: _Field, method_anomaly, window_year_baseline, smoo
         if method_anomaly == "detrend_fixed_baseline":
             _check_reference_period_values(reference_period, cal.year)
             if want_bins is None:  # one chain on the device; the residual field is never materialised
-                r = eng.detrend_fixed_baseline(x, model, pmodel, bool(force_zero_mean), dcal, reference_period)
+                r = eng.detrend_fixed_baseline(x, model, pmodel, bool(force_zero_mean), dcal, reference_period, tails_bins=tails_bins)
             else:  # a bin matrix is wanted: the two stages, the residual mean subtracted by the climatology kernel while it reads
                 d = eng.detrend(x, model, pmodel, bool(force_zero_mean), None, count_invalid=True, defer_mean=True)
                 r = eng.fixed_baseline(d["out"], dcal, reference_period, want_bins, count_invalid=False, sub=d.get("mean"))
@@ -504,7 +513,8 @@ def _anomaly_core(eng, field: _Field, method_anomaly, window_year_baseline, smoo
                          "Use 'detrend_fixed_baseline' for trend removal followed by fixed climatology"],
             context={"provided_method": method_anomaly, "valid_methods": _ANOMALY_METHODS},
         )
-    return {"anom": r["out"], "mask": r["mask"], "invalid": r["invalid_count"], "bins": r.get("bins"), "cal": cal, "dcal": dcal}
+    return {"anom": r["out"], "mask": r["mask"], "invalid": r["invalid_count"], "bins": r.get("bins"), "tails": r.get("tails"),
+            "cal": cal, "dcal": dcal}
 
 
 def _validation_summary(eng, a, own: Optional[slice] = None) -> Dict[str, int]:
@@ -514,7 +524,30 @@ def _validation_summary(eng, a, own: Optional[slice] = None) -> Dict[str, int]:
     return {"n_ocean": int(v[0]), "invalid_total": int(v[1]), "invalid_cells": int(v[2]), "max_invalid": int(v[3])}
 
 
-def _warn_threshold_range(stats: Dict[str, float], bt: binning.BinTable, max_anomaly: float) -> None:
+class _Bounds:
+    """What ``_warn_threshold_range`` reads of a bin table."""
+
+    def __init__(self, lower_bound: float, upper_bound: float):
+        self.lower_bound, self.upper_bound = lower_bound, upper_bound
+
+
+def warn_threshold_stats(thr_stats, n_arrays: int, max_anomaly: float) -> None:
+    """The reference's two threshold-range warnings (detect.py:2711-2730), once per threshold ARRAY of the field: ``thr_stats`` =
+    ``(lower_bound, upper_bound, statistics)`` per block and array, in block order with the ``n_arrays`` arrays of a block
+    (``thresholds``, ``thresholds_stn``) interleaved."""
+    per_table: Dict[tuple, list] = {}
+    for lo, hi, st in thr_stats:
+        per_table.setdefault((lo, hi), []).append(st)
+    for (lo, hi), sts in per_table.items():
+        per_array = [sts[i::n_arrays] for i in range(n_arrays)] if len(sts) >= n_arrays else [sts]
+        for group in per_array:
+            mx = [g["max"] for g in group if g["max"] == g["max"]]
+            mn = [g["min"] for g in group if g["min"] == g["min"]]
+            _warn_threshold_range({"n_too_high": sum(g["n_too_high"] for g in group), "n_too_low": sum(g["n_too_low"] for g in group),
+                                   "max": max(mx) if mx else float("nan"), "min": min(mn) if mn else float("nan")}, _Bounds(lo, hi), max_anomaly)
+
+
+def _warn_threshold_range(stats: Dict[str, float], bt, max_anomaly: float) -> None:
     """The two UserWarnings of detect.py:2711-2730."""
     if stats["n_too_high"] > 0:
         warnings.warn(
@@ -577,6 +610,40 @@ def _extremes_core(eng, a, field, method_extreme, threshold_percentile, window_d
 # ======================================================================================
 # public API
 # ======================================================================================
+def dataset_attrs(method_anomaly="shifting_baseline", method_extreme="hobday_extreme", threshold_percentile=95,
+                  std_normalise=False, detrend_orders=None, window_year_baseline=15, smooth_days_baseline=21,
+                  window_days_hobday=11, window_spatial_hobday=None, reference_period=None, force_zero_mean=True,
+                  method_percentile="approximate", precision=0.01, max_anomaly=5.0, **_other) -> Dict[str, object]:
+    """The Dataset attrs of ``preprocess_data`` exactly as detect.py:731-783 builds them -- a function of the options alone
+    (defaults = those of ``preprocess_data``; options that leave no attr are ignored)."""
+    if detrend_orders is None:
+        detrend_orders = [1]
+    attrs: Dict[str, object] = {
+        "method_anomaly": method_anomaly,
+        "method_extreme": method_extreme,
+        "threshold_percentile": threshold_percentile,
+        "preprocessing_steps": _get_preprocessing_steps(
+            method_anomaly, method_extreme, std_normalise, detrend_orders, window_year_baseline,
+            smooth_days_baseline, window_days_hobday, window_spatial_hobday, reference_period,
+        ),
+    }
+    if method_anomaly == "detrend_harmonic":
+        attrs.update({"detrend_orders": detrend_orders, "force_zero_mean": force_zero_mean, "std_normalise": std_normalise})
+    elif method_anomaly == "shifting_baseline":
+        attrs.update({"window_year_baseline": window_year_baseline, "smooth_days_baseline": smooth_days_baseline})
+    elif method_anomaly == "fixed_baseline":
+        if reference_period is not None:
+            attrs["reference_period"] = list(reference_period)
+    elif method_anomaly == "detrend_fixed_baseline":
+        attrs.update({"detrend_orders": detrend_orders, "force_zero_mean": force_zero_mean})
+        if reference_period is not None:
+            attrs["reference_period"] = list(reference_period)
+    if method_extreme == "hobday_extreme":
+        attrs["window_days_hobday"] = window_days_hobday
+    attrs.update({"method_percentile": method_percentile, "precision": precision, "max_anomaly": max_anomaly})
+    return attrs
+
+
 def preprocess_data(
     da,
     method_anomaly: Literal["detrend_harmonic", "shifting_baseline", "fixed_baseline", "detrend_fixed_baseline"] = "shifting_baseline",
@@ -605,13 +672,16 @@ def preprocess_data(
     devices: Optional[List[int]] = None,
     _validation: str = "raise",
     _own_rows: Optional[Tuple[int, int]] = None,
+    _defer_warnings: bool = False,
 ):
     """Anomalies, thresholds and the boolean extreme mask of a (time, [lat,] lon / cells) field.
 
     ``_validation="return"`` (internal: :mod:`marex_amd.dask_adapter` runs one spatial block of a larger field per call): the
     verdict of ``_validate_data_values`` is not raised but returned as ``ds.attrs["_validation"]`` -- a block may be all land,
     and the error is about the whole field; ``_own_rows=(r0, r1)``: the grid rows (cells on a mesh) of the block its counts
-    are about -- the others are overlap rows.
+    are about -- the others are overlap rows (the call then runs as ONE device block: a caller that cuts the field itself sizes its
+    blocks to the HBM); ``_defer_warnings``: the threshold-range statistics (detect.py:2711-2730) are returned as
+    ``ds.attrs["_thr_stats"]`` instead of being warned about, so that a caller with several blocks warns once for the field.
 
     ``devices=[0, 1, ...]`` (extension): the field is cut into at least that many spatial blocks (latitude bands
     with ``ws//2`` overlap rows / cell ranges -- cells are independent along time) and every listed device works through its
@@ -679,7 +749,23 @@ def preprocess_data(
         engines.append(get_engine(dv, seen.get(dv, 0)))
         seen[dv] = seen.get(dv, 0) + 1
     eng = engines[0]
-    blocks = plan_blocks(field, eng, halo, int(per_cell * 1.25), min_blocks=len(engines), engines=engines)
+    if _own_rows is not None:
+        # the caller's block IS the device block: its overlap rows must not be cut again (they would be counted twice)
+        from .dist import plan_shards as _plan_shards
+
+        blocks = _plan_shards(field.ny if field.gridded else 0, field.nx, 1, halo)
+        if eng.device.type == "cuda":
+            import torch as _torch
+
+            free = int(_torch.cuda.mem_get_info(eng.device)[0])
+            if blocks[0].cells_in * int(per_cell * 1.25) > free:
+                raise ProcessingError(
+                    "Spatial block does not fit the device",
+                    details=f"{blocks[0].cells_in} cells x {int(per_cell * 1.25)} bytes per cell, {free} bytes of HBM free",
+                    suggestions=["use smaller blocks (block_rows / block_cells of preprocess_data_lazy)"],
+                )
+    else:
+        blocks = plan_blocks(field, eng, halo, int(per_cell * 1.25), min_blocks=len(engines), engines=engines)
     single = len(blocks) == 1
     if not single:
         logger.info(f"Field processed in {len(blocks)} spatial blocks of <= {max(b.cells_in for b in blocks)} cells"
@@ -730,6 +816,8 @@ def preprocess_data(
                                  int(ws_eff) if ws_eff else 1, int(fb.shape[1]))
                 if what == "tails":
                     return need_bins if (k is not None and e.shifting_tails_ok(dcal)) else None
+                if what == "tails_fixed":
+                    return need_bins if k is not None else None
                 return need_bins if k is None else None
 
         a = _anomaly_core(e, fb, method_anomaly, window_year_baseline, smooth_days_baseline, detrend_orders,
@@ -814,17 +902,9 @@ def preprocess_data(
     if method_anomaly == "shifting_baseline":
         logger.info(f"Trimming data to start from {cal.min_year + window_year_baseline} (removing first {window_year_baseline} years)")
     # the reference's two threshold-range warnings, once per threshold array (detect.py:2711-2730)
-    per_table: Dict[tuple, list] = {}
-    for st, table in defer["stats"]:
-        per_table.setdefault((table.lower_bound, table.upper_bound), [table, []])[1].append(st)
-    n_arrays = 2 if want_stn else 1
-    for table, sts in per_table.values():
-        per_array = [sts[i::n_arrays] for i in range(n_arrays)] if len(sts) >= n_arrays else [sts]
-        for group in per_array:
-            mx = [g["max"] for g in group if g["max"] == g["max"]]
-            mn = [g["min"] for g in group if g["min"] == g["min"]]
-            _warn_threshold_range({"n_too_high": sum(g["n_too_high"] for g in group), "n_too_low": sum(g["n_too_low"] for g in group),
-                                   "max": max(mx) if mx else float("nan"), "min": min(mn) if mn else float("nan")}, table, max_anomaly)
+    thr_stats = [(float(table.lower_bound), float(table.upper_bound), dict(st)) for st, table in defer["stats"]]
+    if not _defer_warnings:
+        warn_threshold_stats(thr_stats, 2 if want_stn else 1, max_anomaly)
     if not single:
         n_true_total = int(np.count_nonzero(out["extreme_events"]))
 
@@ -853,32 +933,16 @@ def preprocess_data(
     if cell_areas is not None:
         ds["cell_areas"] = cell_areas.astype(np.float32)
 
-    # attrs exactly as detect.py:731-783
-    ds.attrs.update({
-        "method_anomaly": method_anomaly,
-        "method_extreme": method_extreme,
-        "threshold_percentile": threshold_percentile,
-        "preprocessing_steps": _get_preprocessing_steps(
-            method_anomaly, method_extreme, std_normalise, detrend_orders, window_year_baseline,
-            smooth_days_baseline, window_days_hobday, window_spatial_hobday, reference_period,
-        ),
-    })
-    if method_anomaly == "detrend_harmonic":
-        ds.attrs.update({"detrend_orders": detrend_orders, "force_zero_mean": force_zero_mean, "std_normalise": std_normalise})
-    elif method_anomaly == "shifting_baseline":
-        ds.attrs.update({"window_year_baseline": window_year_baseline, "smooth_days_baseline": smooth_days_baseline})
-    elif method_anomaly == "fixed_baseline":
-        if reference_period is not None:
-            ds.attrs["reference_period"] = list(reference_period)
-    elif method_anomaly == "detrend_fixed_baseline":
-        ds.attrs.update({"detrend_orders": detrend_orders, "force_zero_mean": force_zero_mean})
-        if reference_period is not None:
-            ds.attrs["reference_period"] = list(reference_period)
-    if method_extreme == "hobday_extreme":
-        ds.attrs["window_days_hobday"] = window_days_hobday
-    ds.attrs.update({"method_percentile": method_percentile, "precision": precision, "max_anomaly": max_anomaly})
+    ds.attrs.update(dataset_attrs(
+        method_anomaly=method_anomaly, method_extreme=method_extreme, threshold_percentile=threshold_percentile,
+        std_normalise=std_normalise, detrend_orders=detrend_orders, window_year_baseline=window_year_baseline,
+        smooth_days_baseline=smooth_days_baseline, window_days_hobday=window_days_hobday,
+        window_spatial_hobday=window_spatial_hobday, reference_period=reference_period, force_zero_mean=force_zero_mean,
+        method_percentile=method_percentile, precision=precision, max_anomaly=max_anomaly))
     if _validation != "raise":
         ds.attrs["_validation"] = dict(total)
+    if _defer_warnings:
+        ds.attrs["_thr_stats"] = thr_stats
     logger.info(f"Preprocessing completed successfully - {n_true_total} extreme events identified")
     return ds
 

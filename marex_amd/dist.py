@@ -142,7 +142,23 @@ class EngineSet:
 
     @property
     def ctx(self):
+        """The FIRST engine's context (timers of that engine, debug counters).  Options set through it reach only that engine:
+        use :meth:`set_option` / :meth:`options`, which fan out to all of them."""
         return self.engines[0].ctx
+
+    def set_option(self, name: str, value) -> None:
+        """``ctx.set_option`` on every engine (``None`` clears it): a forced kernel path holds for every band of the set."""
+        for e in self.engines:
+            e.ctx.set_option(name, value)
+
+    def options(self, **opts):
+        """``with es.options(NAME=v, ...):`` -- the options on every engine, previous values restored on exit."""
+        from contextlib import ExitStack
+
+        stack = ExitStack()
+        for e in self.engines:
+            stack.enter_context(e.ctx.options(**opts))
+        return stack
 
     def set_hobday_path(self, path) -> None:
         for e in self.engines:
@@ -189,8 +205,10 @@ def _one_shard(hot, sh, x, dcal, *, W, S, bins, q, wd, ws, nx, workspace, detren
         r = hot.shifting_hobday(x, dcal, W=W, S=S, bins=bins, q=q, wd=wd, ws=ws, ny=ny_s, nx=nx_s, own_rows=rows,
                                 workspace=workspace)
     else:
-        f = hot.detrend_fixed_baseline(x, detrend[0], detrend[1], True, dcal, None, wsp=workspace)
-        h = hot.hobday_approx(f["out"], dcal, bins, q, wd, ws, ny_s, nx_s, rows=rows, cells=(own.start, own.stop), wsp=workspace)
+        tails_bins = bins if hot.tails_plan(dcal, bins, q, wd, ws, x.shape[1]) is not None else None
+        f = hot.detrend_fixed_baseline(x, detrend[0], detrend[1], True, dcal, None, wsp=workspace, tails_bins=tails_bins)
+        h = hot.hobday_approx(f["out"], dcal, bins, q, wd, ws, ny_s, nx_s, rows=rows, cells=(own.start, own.stop), wsp=workspace,
+                              tails=f.get("tails"))
         r = {"dat_anomaly": f["out"], "mask": f["mask"], "invalid_count": f["invalid_count"], "thr_doy_major": h["thr_doy_major"],
              "stats_dev": h["stats_dev"], "extreme_events": h["extreme"], "n_true": h["n_true"], "path": h["path"]}
     vs = hot.validation_summary(r["mask"], r["invalid_count"], (own.start, own.stop), workspace)  # a3 verdict
@@ -270,7 +288,8 @@ def broadcast_tables(tables: Optional[Dict[str, object]], src: int = 0, device=N
     if rank == src:
         manifest = {"arrays": [], "scalars": {}}
         for name, v in (tables or {}).items():
-            if isinstance(v, np.ndarray):
+            # arrays of plain numbers travel packed; object arrays (cftime axes) and 0-d arrays go with the pickled manifest
+            if isinstance(v, np.ndarray) and v.dtype != object and v.ndim >= 1:
                 a = np.ascontiguousarray(v)
                 manifest["arrays"].append((name, a.dtype.str, tuple(a.shape), off, a.nbytes))
                 chunks.append(a.view(np.uint8).reshape(-1) if a.dtype != np.bool_ else a.astype(np.uint8).reshape(-1))

@@ -20,6 +20,30 @@ from .calendar import N_DOY, CalendarPlan
 from .exceptions import ConfigurationError, ProcessingError
 
 
+import logging
+
+_log = logging.getLogger("marex_amd")
+_noted: set = set()
+
+
+def _note_path(msg: str) -> None:
+    """INFO, once per distinct message: a call took a slower kernel family than the tuned one (same results; README "kernel
+    families") -- so that a user with, say, smooth_days_baseline=31 sees why the anomaly stage runs at a quarter of the speed."""
+    if msg not in _noted:
+        _noted.add(msg)
+        _log.info(msg)
+
+
+def shifting_kernel_family(W: int, S: int, C: int, lists: bool) -> str:
+    """Which anomaly kernel ``marex_shifting_baseline[_tails]_f32`` takes for a gap-free daily calendar (csrc/marex_shifting.hip:
+    ``lean_instance`` / ``fast_ws``; irregular calendars send single chunks to the general kernel on top of this)."""
+    fast_w = W in (3, 4, 5, 6, 7, 10, 13, 15)
+    fast = fast_w if S == 21 else (S in (11, 15) and W in (5, 10, 15))
+    if S == 21 and W in (5, 15) and C >= 4 and C % 4 == 0:
+        return "lean"
+    return "fast" if fast else "general"
+
+
 def _key_to_float(key: int) -> float:
     """Inverse of the order-preserving uint32 key used for the device-side min / max of thresholds."""
     bits = (key & 0x7FFFFFFF) if (key & 0x80000000) else (~key & 0xFFFFFFFF)
@@ -259,6 +283,12 @@ class HotPath:
             return None  # the lists are read from the top: a low quantile walks most of every list (the public API stops at 60 %)
         return nd  # ws == 1: the per-cell threshold kernel (no tiles), any record length
 
+    def fused_tails_ok(self, dcal: DeviceCalendar, bins: BinTable) -> bool:
+        """The fixed-baseline kernels (plain and behind the detrend fit) emit the key lists of their own output for buckets of at
+        most 128 rows and tables of at most 511 bins (option FIXED_TAILS=0: never -- the extraction pass then makes them)."""
+        nd = int(np.diff(dcal.plan.doy_start).max())
+        return bool(self.ctx_opt("FIXED_TAILS", 1)) and bool(self.ctx_opt("FIXED_REG", 1)) and 1 <= nd <= 128 and bins.nb <= 511
+
     def _tail_buffers(self, nd: int, list_rows: int, Cn: int, wsp: Optional[dict]):
         nper = (nd + list_rows - 1) // list_rows
         nch = 2 if list_rows <= 16 else 4
@@ -447,6 +477,15 @@ class HotPath:
         mask are produced for the owned rows only (:mod:`marex_amd.dist`).
         """
         K = self.tails_plan(dcal, bins, q, wd, ws, x.shape[1])
+        fam = shifting_kernel_family(int(W), int(S), int(x.shape[1]), K is not None)
+        if fam != "lean":
+            _note_path(f"shifting_baseline: window_year_baseline={W}, smooth_days_baseline={S}, {x.shape[1]} cells take the "
+                       f"'{fam}' anomaly kernel (tuned path: smooth_days_baseline=21, window_year_baseline in (5, 15), cells a "
+                       "multiple of 4; same results)")
+        if K is None:
+            nd = int(np.diff(dcal.plan.doy_start).max())
+            _note_path(f"hobday_extreme: dayofyear buckets of {nd} rows with window_spatial_hobday={ws}, q={q} take the bin-matrix "
+                       "threshold kernels (sorted key lists need >= 24 rows per bucket or no spatial pooling; same results)")
         if K is not None and self.shifting_tails_ok(dcal):
             a = self.shifting_baseline_tails(x, dcal, W, S, bins, wsp=workspace)
         else:
@@ -480,11 +519,14 @@ class HotPath:
         wsp: Optional[dict] = None,
         sub: Optional[torch.Tensor] = None,
         second_stage: bool = False,
+        tails_bins: Optional[BinTable] = None,
     ) -> Dict[str, torch.Tensor]:
         """``x - nanmean_doy(x)`` for all timesteps (detect.py:2299-2397); ``dcal`` must be an untrimmed calendar.
         ``sub`` ``[C]``: a per-cell value taken off ``x`` on load (the deferred residual mean of :meth:`detrend`).
         ``second_stage``: called on the output of :meth:`detrend` with a shared workspace -- its mask / count buffers get
-        names of their own, so that the first stage's validation outputs (the RAW field's) survive."""
+        names of their own, so that the first stage's validation outputs (the RAW field's) survive.
+        ``tails_bins``: also leave the sorted key lists of the output (``"tails"``, 32 rows per list: what
+        :meth:`tail_extract` would make of it) when the register kernel takes the shape -- see :meth:`fused_tails_ok`."""
         self._bind_stream()
         T, Cn = x.shape
         cal = dcal.plan
@@ -496,6 +538,22 @@ class HotPath:
         mask = self._buf(wsp, "mask2" if second_stage else "mask", (Cn,), torch.uint8, self.device)
         invalid = self._buf(wsp, "invalid2" if second_stage else "invalid", (Cn,), torch.int32, self.device)
         invalid.zero_()
+        if tails_bins is not None and bins is None and self.fused_tails_ok(dcal, tails_bins):
+            if sub is not None:
+                assert sub.dtype == torch.float32 and sub.numel() == Cn
+            edges = self.bin_tables(tails_bins)[0]
+            nd = int(np.diff(cal.doy_start).max())
+            lists, aux = self._tail_buffers(nd, self.LIST_ROWS_EXTRACT, Cn, wsp)
+            rc = self.lib.marex_fixed_baseline_tails_f32(
+                self.ctx.handle, x.data_ptr(), sub.data_ptr() if sub is not None else None, nd, T, Cn, dcal.doy_start.data_ptr(),
+                dcal.doy_rows.data_ptr(), use.data_ptr() if use is not None else None, edges.data_ptr(), tails_bins.nb,
+                out.data_ptr(), mask.data_ptr(), invalid.data_ptr() if count_invalid else None, lists.data_ptr(), aux.data_ptr(),
+            )
+            self.ctx.check(rc, "marex_fixed_baseline_tails_f32")
+            if use is not None:
+                self.sync()
+            return {"out": out, "mask": mask, "invalid_count": invalid,
+                    "tails": {"tails": lists, "aux": aux, "max_bucket": nd, "list_rows": self.LIST_ROWS_EXTRACT, "_keep": edges}}
         if bins is not None:
             edges = self.bin_tables(bins)[0]
             binsb = self._buf(wsp, "bins", self.bins_shape(T, Cn), torch.int16, self.device)
@@ -575,7 +633,8 @@ class HotPath:
         return res
 
     def detrend_fixed_baseline(self, x: torch.Tensor, model: np.ndarray, pmodel: np.ndarray, force_zero_mean: bool,
-                               dcal: DeviceCalendar, reference_period=None, wsp: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+                               dcal: DeviceCalendar, reference_period=None, wsp: Optional[dict] = None,
+                               tails_bins: Optional[BinTable] = None) -> Dict[str, torch.Tensor]:
         """``detrend_fixed_baseline`` (detect.py:2400-2462): residual of the fit minus its daily climatology.  One chain on the
         device when the model has at most 5 terms and dayofyear buckets at most 128 rows (the residual field is never
         materialised: 3 reads and 1 write of the field), otherwise the two stages one after the other.  Same bits either way."""
@@ -586,8 +645,11 @@ class HotPath:
         if n_coef > 5 or nd > 128 or not self.ctx_opt("DETREND_FUSED", 1):
             d = self.detrend(x, model, pmodel, bool(force_zero_mean), None, count_invalid=True, wsp=wsp, defer_mean=True)
             r = self.fixed_baseline(d["out"], dcal, reference_period, None, count_invalid=False, wsp=wsp, sub=d.get("mean"),
-                                    second_stage=True)
-            return {"out": r["out"], "mask": d["mask"], "invalid_count": d["invalid_count"]}
+                                    second_stage=True, tails_bins=tails_bins)
+            res = {"out": r["out"], "mask": d["mask"], "invalid_count": d["invalid_count"]}
+            if "tails" in r:
+                res["tails"] = r["tails"]
+            return res
         self._bind_stream()
         assert x.dtype == torch.float32 and x.is_contiguous() and cal.T == T and cal.T_out == T
         pm = self._dev(np.ascontiguousarray(pmodel, dtype=np.float64))
@@ -600,14 +662,26 @@ class HotPath:
         out = self._buf(wsp, "anom", (T, Cn), torch.float32, self.device)
         mask = self._buf(wsp, "mask", (Cn,), torch.uint8, self.device)
         invalid = self._buf(wsp, "invalid", (Cn,), torch.int32, self.device)
-        rc = self.lib.marex_detrend_fixed_baseline_f32(
-            self.ctx.handle, x.data_ptr(), T, Cn, pm.data_ptr(), mt.data_ptr(), mts.data_ptr(), n_coef, int(bool(force_zero_mean)),
-            dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), use.data_ptr() if use is not None else None, nd,
-            out.data_ptr(), mask.data_ptr(), invalid.data_ptr(),
-        )
-        self.ctx.check(rc, "marex_detrend_fixed_baseline_f32")
+        res = {"out": out, "mask": mask, "invalid_count": invalid}
+        if tails_bins is not None and self.fused_tails_ok(dcal, tails_bins):
+            edges = self.bin_tables(tails_bins)[0]
+            lists, aux = self._tail_buffers(nd, self.LIST_ROWS_EXTRACT, Cn, wsp)
+            rc = self.lib.marex_detrend_fixed_baseline_tails_f32(
+                self.ctx.handle, x.data_ptr(), T, Cn, pm.data_ptr(), mt.data_ptr(), mts.data_ptr(), n_coef, int(bool(force_zero_mean)),
+                dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), use.data_ptr() if use is not None else None, nd,
+                edges.data_ptr(), tails_bins.nb, out.data_ptr(), mask.data_ptr(), invalid.data_ptr(), lists.data_ptr(), aux.data_ptr(),
+            )
+            self.ctx.check(rc, "marex_detrend_fixed_baseline_tails_f32")
+            res["tails"] = {"tails": lists, "aux": aux, "max_bucket": nd, "list_rows": self.LIST_ROWS_EXTRACT, "_keep": edges}
+        else:
+            rc = self.lib.marex_detrend_fixed_baseline_f32(
+                self.ctx.handle, x.data_ptr(), T, Cn, pm.data_ptr(), mt.data_ptr(), mts.data_ptr(), n_coef, int(bool(force_zero_mean)),
+                dcal.doy_start.data_ptr(), dcal.doy_rows.data_ptr(), use.data_ptr() if use is not None else None, nd,
+                out.data_ptr(), mask.data_ptr(), invalid.data_ptr(),
+            )
+            self.ctx.check(rc, "marex_detrend_fixed_baseline_f32")
         self.sync()  # pm / mt / use must outlive the kernels
-        return {"out": out, "mask": mask, "invalid_count": invalid}
+        return res
 
     # ------------------------------------------------------------------ stage a9 exact Hobday
     def std_normalise(self, anom: torch.Tensor, dcal: DeviceCalendar, window: int = 30,

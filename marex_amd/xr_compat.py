@@ -152,6 +152,7 @@ class _MiniDataset:
         self.data_vars: Dict[str, _MiniDataArray] = {}
         self.coords: Dict[str, _MiniDataArray] = {}
         self.attrs: Dict[str, Any] = dict(attrs or {})
+        self.encoding: Dict[str, Any] = {}  # like xarray's: never written by a store
         for k, v in (coords or {}).items():
             self.coords[k] = _as_coord(k, v, ())
         for k, v in (data_vars or {}).items():

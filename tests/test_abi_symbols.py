@@ -84,3 +84,28 @@ def test_ctypes_prototypes_match_the_header_parameter_lists():
     for name, (_, argtypes) in _lib.PROTOTYPES.items():
         got = ["ptr" if (a not in kind_of) else kind_of[a] for a in argtypes]  # POINTER(...) types count as pointers
         assert got == sigs[name], f"{name}: binding {got} != header {sigs[name]}"
+
+
+def test_workspace_bytes_matches_what_the_engine_allocates():
+    """marex_workspace_bytes: a C caller can size every buffer of a block without reading engine.py -- the numbers
+    are the shapes `HotPath` allocates (lists [366][NPER][nch][C][8 x u16], aux [366][C] u32, blocked bin matrix ...)."""
+    import ctypes as C
+
+    from marex_amd.engine import HotPath
+
+    class Cfg(C.Structure):
+        _fields_ = [("T", C.c_int64), ("T_out", C.c_int64), ("C", C.c_int64), ("max_bucket", C.c_int), ("list_rows", C.c_int)]
+
+    lib = _lib.load()
+    out = (C.c_size_t * 8)()
+    T, T_out, Cn = 36500, 31022, 124 * 1440
+    assert lib.marex_workspace_bytes(C.byref(Cfg(T, T_out, Cn, 85, 15)), out) == 0
+    nper = lib.marex_tail_lists(85, 15)
+    assert nper == 6
+    assert out[0] == T_out * Cn * 4 and out[1] == T_out * Cn and out[2] == 366 * Cn * 4
+    assert out[3] == 366 * nper * 2 * Cn * 16 and out[4] == 366 * Cn * 4 and out[5] == 0 and out[6] == Cn * 5
+    assert out[7] == out[0] + out[1] + 2 * out[2] + out[3] + out[4] + out[6]
+    assert lib.marex_workspace_bytes(C.byref(Cfg(3652, 1826, 1000, 5, 0)), out) == 0     # bin-matrix path
+    nblk, rows, w = HotPath.bins_shape(1826, 1000)
+    assert out[5] == nblk * rows * w * 2 and out[3] == 0 and out[4] == 0
+    assert lib.marex_workspace_bytes(None, out) != 0 and lib.marex_workspace_bytes(C.byref(Cfg(10, 20, 5, 5, 0)), out) != 0

@@ -134,13 +134,17 @@ def _bcast_worker(rank, world, port, out_dir):
         model, pmodel = calendar.detrend_model(calendar.decimal_year(tm), [1, 2], True)
         tables = calendar.plan_tables(cal)
         tables.update({"bins.edges": bt.edges, "bins.centres": bt.centres, "bins.precision": 0.01, "detrend.model": model,
-                       "detrend.pmodel": pmodel, "empty": np.zeros((0, 3), dtype=np.float32)})
+                       "detrend.pmodel": pmodel, "empty": np.zeros((0, 3), dtype=np.float32),
+                       # what the packed byte path cannot carry goes with the manifest: object arrays (cftime axes), 0-d arrays
+                       "objs": np.array(["1999-03-01", None, 3], dtype=object), "zero_d": np.array(2.5, dtype=np.float64)})
     got = broadcast_tables(tables, src=0, host_collectives=True)
     cal = calendar.plan_from_tables(got)
     np.savez(os.path.join(out_dir, f"bc{rank}.npz"), year_plan=cal.year_plan(), kept=cal.kept, doy_rows=cal.doy_rows, time=cal.time.astype("int64"),
              edges=got["bins.edges"], centres=got["bins.centres"], model=got["detrend.model"], pmodel=got["detrend.pmodel"],
              scal=np.array([cal.min_year, cal.n_cal_years, cal.first_valid_year_idx, int(cal.has_duplicates), cal.T_out]),
-             prec=np.array([got["bins.precision"]]), empty_shape=np.array(got["empty"].shape))
+             prec=np.array([got["bins.precision"]]), empty_shape=np.array(got["empty"].shape),
+             objs_ok=np.array([got["objs"].dtype == object and list(got["objs"]) == ["1999-03-01", None, 3]
+                               and got["zero_d"].shape == () and float(got["zero_d"]) == 2.5]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -161,5 +165,77 @@ def test_tables_broadcast_from_rank_zero(tmp_path):
         assert np.array_equal(p["time"], cal.time.astype("int64"))
         assert p["edges"].dtype == np.float32 and p["edges"].tobytes() == bt.edges.tobytes() and p["centres"].tobytes() == bt.centres.tobytes()
         assert p["model"].tobytes() == model.tobytes() and p["pmodel"].tobytes() == pmodel.tobytes()
+        assert bool(p["objs_ok"][0])
         assert list(p["scal"]) == [cal.min_year, cal.n_cal_years, cal.first_valid_year_idx, 0, cal.T_out]
         assert float(p["prec"][0]) == 0.01 and list(p["empty_shape"]) == [0, 3]
+
+
+def _bands_worker(rank, world, port, ny, nx, W, nbands, out_dir):
+    """What a rank of `bench.py --gpus N` does with the 100-yr field, at toy size: bands rank, rank + N, ... of `nbands` latitude
+    bands, one `shard_step` over them, the scalar all-reduce."""
+    import torch
+    import torch.distributed as dist
+
+    from marex_amd.dist import SUMMARY_KEYS, allreduce_step, shard_step
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tm = calendar.daily_time_axis("2003-01-01", 9 * 365 + 2)
+    cal = calendar.build_calendar(tm, window_year_baseline=W)
+    bt = binning.hobday_bins()
+    all_shards = plan_shards(ny, nx, nbands, 2)
+    shards = [all_shards[i] for i in range(rank, nbands, world)]
+    xs = [torch.from_numpy(synth.synth_field(synth.make_tables(tm, s.ny_in, nx, lat_range=(s.in0, s.in1, ny)), cell_base=s.cell_base))
+          for s in shards]
+    parts = []
+
+    class Keep(OracleEngine):  # shard_step hands back the last shard's result only: keep every band's thresholds
+        def shifting_hobday(self, x, dcal, **kw):
+            r = super().shifting_hobday(x, dcal, **kw)
+            parts.append(r["thr_doy_major"].numpy())
+            return r
+
+    _, local, mx = shard_step(Keep(), shards, xs, cal, W=W, S=21, bins=bt, q=0.95, wd=11, ws=5, nx=nx)
+    local, mx = allreduce_step(local, mx, host_collectives=True)
+    np.savez(os.path.join(out_dir, f"b{rank}.npz"), summ=np.array([int(v) for v in local.tolist()] + [int(mx[0])]),
+             keys=np.array(SUMMARY_KEYS), **{f"thr{i}": p for i, p in zip(range(rank, nbands, world), parts)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_band_assignment_and_reduction_at_the_scale_runs_rank_counts(tmp_path, world):
+    """The driver's scaling run uses N = 1, 2, 4, 8 ranks; at N = 4 and 8 bench.py cuts the field into 8 bands and rank r takes
+    bands r, r + N, ...  Same assignment, same `shard_step` + all-reduce here with the oracle as the engine: every owned row is
+    computed exactly once, the reduced counters are the field's, on every rank (a one-GPU box cannot hold 4 or 8 GPU ranks of
+    the 100-yr field -- 8 exceed its process limit -- so this is where those rank counts are rehearsed)."""
+    import importlib.util
+
+    from oracle import marex_oracle as orc
+
+    spec = importlib.util.spec_from_file_location("bench_for_bands", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    nbands = bench.band_count(world)
+    assert nbands == 8
+    ny, nx, W = 48, 8, 4   # 8 bands of 6 rows, 2 overlap rows per interior side
+    mp.spawn(_bands_worker, args=(world, _free_port(), ny, nx, W, nbands, str(tmp_path)), nprocs=world, join=True)
+    tm = calendar.daily_time_axis("2003-01-01", 9 * 365 + 2)
+    cal = calendar.build_calendar(tm, window_year_baseline=W)
+    bt = binning.hobday_bins()
+    x = synth.synth_field(synth.make_tables(tm, ny, nx))
+    ref = orc.preprocess_arrays(x, cal, ny=ny, nx=nx, window_year_baseline=W, edges=bt.edges, centres=bt.centres)
+    v = orc.validate_data_values(x)
+    shards = plan_shards(ny, nx, nbands, 2)
+    thr = {}
+    for r in range(world):
+        p = np.load(tmp_path / f"b{r}.npz")
+        summ = dict(zip([str(k) for k in p["keys"]], p["summ"][:-1]))
+        assert summ["n_ocean"] == v["n_ocean"] and summ["n_extreme"] == int(ref["extreme_events"].sum()) and summ["thr_unresolved"] == 0
+        assert summ["invalid_total"] == v["total_invalid_in_ocean"] and int(p["summ"][-1]) == v["max_invalid"]
+        for i in range(r, nbands, world):
+            assert i not in thr
+            thr[i] = p[f"thr{i}"]
+    assert sorted(thr) == list(range(nbands))
+    assert np.array_equal(stitch_cells([thr[i] for i in range(nbands)], shards), ref["thresholds"].T, equal_nan=True)

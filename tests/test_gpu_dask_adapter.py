@@ -126,6 +126,81 @@ def test_lazy_bands_equal_the_eager_call(hot, dsa, kw):
     same(eager, lazy)
     assert v["n_ocean"] == int(np.asarray(eager["mask"].values).sum()) and v["max_invalid"] == 0
     assert np.array_equal(np.asarray(lazy["dat_anomaly"].coords["time"].values), np.asarray(eager["dat_anomaly"].coords["time"].values))
+    # the attrs of the eager Dataset (detect.py:731-783), nothing in them that a zarr / netCDF writer cannot store
+    assert dict(lazy.attrs) == dict(eager.attrs)
+    import json
+
+    json.dumps(dict(lazy.attrs))
+    if kw["method_anomaly"] == "shifting_baseline":
+        # ... and the ORACLE itself, not only the eager HIP call: the block planning, the overlap rows and the stitching are part
+        # of what is compared (detect.py:2617-2620, 785-808, 2708-2732)
+        from marex_amd import binning
+        from oracle import marex_oracle as orc
+
+        T, ny, nx = x.shape
+        cal = calendar.build_calendar(tm, window_year_baseline=kw["window_year_baseline"])
+        bt = binning.hobday_bins()
+        exp = orc.preprocess_arrays(x.reshape(T, ny * nx), cal, ny=ny, nx=nx, window_year_baseline=kw["window_year_baseline"],
+                                    smooth_days_baseline=21, window_days_hobday=11, window_spatial_hobday=5,
+                                    threshold_percentile=95.0, edges=bt.edges, centres=bt.centres)
+        assert np.array_equal(np.asarray(lazy["dat_anomaly"].values).reshape(cal.T_out, -1), exp["dat_anomaly"], equal_nan=True)
+        assert np.array_equal(np.asarray(lazy["thresholds"].values).reshape(ny * nx, 366), exp["thresholds"], equal_nan=True)
+        assert np.array_equal(np.asarray(lazy["extreme_events"].values).reshape(cal.T_out, -1), exp["extreme_events"])
+        assert np.array_equal(np.asarray(lazy["mask"].values).reshape(-1), exp["mask"])
+
+
+def test_one_threshold_range_warning_for_the_whole_field(hot, dsa):
+    """Cells with a constant anomaly (sea ice) put thresholds below the table's lower bound in SEVERAL blocks: the eager call warns
+    once (detect.py:2711-2730), and so does the lazy Dataset -- when its thresholds are computed, with the field's minimum."""
+    from marex_amd.dask_adapter import preprocess_data_lazy
+
+    tm, x, coords = gridded(ny=17, nx=16, years=12)
+    x[:, 0:5, 2:9] = np.float32(271.35)      # a constant patch (whole 5 x 5 neighbourhoods) in the first block
+    x[:, 11:16, 3:12] = np.float32(271.35)   # ... and one across the third and the fourth
+    kw = dict(method_anomaly="shifting_baseline", method_extreme="hobday_extreme", window_year_baseline=5)
+    with warnings.catch_warnings(record=True) as w_eager:
+        warnings.simplefilter("always")
+        marex_amd.preprocess_data(DataArray(x, dims=("time", "lat", "lon"), coords=coords), **kw)
+    low_e = [str(m.message) for m in w_eager if "below expected range" in str(m.message)]
+    assert len(low_e) == 1
+    with warnings.catch_warnings(record=True) as w_lazy:
+        warnings.simplefilter("always")
+        lazy = preprocess_data_lazy(DataArray(dsa.from_array(x, chunks=(100, 5, 16)), dims=("time", "lat", "lon"), coords=coords),
+                                    block_rows=5, **kw)
+        assert not [m for m in w_lazy if "below expected range" in str(m.message)]   # nothing has run yet
+        np.asarray(lazy["thresholds"].data.compute())
+    low_l = [str(m.message) for m in w_lazy if "below expected range" in str(m.message)]
+    assert low_l == low_e  # one warning, the same text (the field's minimum, not a block's)
+
+
+def test_blocks_from_a_thread_pool_on_one_device(hot):
+    """Dask's threaded scheduler runs ``run_block`` tasks of the same device concurrently (blocks i and i + len(devices)): four
+    unequal blocks from four threads at once, all on device 0 -- serialised inside ``run_block`` (one engine, one stream binding,
+    scratch that grows with the block) -- give the eager Dataset."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from marex_amd.dask_adapter import plan_spatial_blocks, run_block
+
+    tm, x, coords = gridded(ny=23, nx=16, years=12)
+    kw = dict(method_anomaly="shifting_baseline", method_extreme="hobday_extreme", window_year_baseline=5,
+              dimensions={"time": "time", "x": "lon", "y": "lat"}, coordinates={"time": "time", "x": "lon", "y": "lat"})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        eager = marex_amd.preprocess_data(DataArray(x, dims=("time", "lat", "lon"), coords=coords), **kw)
+        shards = plan_spatial_blocks(23, 16, 2, block_rows=7)            # 7 + 6 + 5 + 5 rows: unequal, with overlap rows
+        assert len({s.in1 - s.in0 for s in shards}) > 1 and len(shards) >= 3
+
+        def one(sh):
+            bc = {"lat": coords["lat"][sh.in0:sh.in1], "lon": coords["lon"]}
+            return run_block(x[:, sh.in0:sh.in1], tm, sh, True, ("time", "lat", "lon"), bc, kw, 0)
+
+        with ThreadPoolExecutor(max_workers=len(shards)) as pool:
+            res = list(pool.map(one, shards))
+    for name, axis in (("dat_anomaly", 1), ("extreme_events", 1), ("mask", 0), ("thresholds", 0)):
+        got = np.concatenate([r[name] for r in res], axis=axis)
+        exp = np.asarray(eager[name].values)
+        assert got.shape == exp.shape and np.array_equal(got, exp, equal_nan=got.dtype.kind == "f"), name
+    assert sum(r["_validation"]["n_ocean"] for r in res) == int(np.asarray(eager["mask"].values).sum())
 
 
 def test_lazy_cell_ranges_on_a_mesh_and_validation(hot, dsa):

@@ -264,3 +264,55 @@ def test_outliers_beyond_the_table_stay_on_the_list_path(hot, per_bucket):
     for list_rows, ws, ny, nx in ((15, 5, 12, 16), (32, 5, 12, 16), (15, None, 0, 12 * 16)):
         c = _thr_case(hot, anom, cal, bt, 95.0, 11, ws, ny, nx, list_rows=list_rows)
         assert (c[4] == 0) == (per_bucket <= 2), (per_bucket, c)
+
+
+@pytest.mark.parametrize("years,C", [(12, 300), (40, 257), (60, 130), (100, 64)])
+def test_fixed_baseline_kernels_emit_the_tails_of_their_own_output(hot, years, C):
+    """marex_fixed_baseline_tails_f32 / marex_detrend_fixed_baseline_tails_f32: the anomalies of the plain entry points, and key
+    lists + aux words that are BYTE for byte what the extraction kernel makes of those anomalies (32 rows per list; buckets of
+    12 / 40 rows: the 48-row register kernel, one / two lists; 60 / 100 rows: the 128-row kernel, two / four lists) -- NaN gaps,
+    land, +-inf, values beyond the table, ties."""
+    rng = np.random.default_rng(100 + years)
+    tm = calendar.daily_time_axis("1950-03-01", years * 365 + years // 4)
+    cal = calendar.build_calendar(tm)
+    x = (rng.normal(0, 0.9, (len(tm), C)) + 3.0 * np.sin(2 * np.pi * cal.doy / 365.25)[:, None]
+         + 0.0004 * np.arange(len(tm))[:, None]).astype(np.float32)
+    pick = rng.random(x.shape)
+    x[pick < 0.01] = np.nan
+    x[(pick > 0.01) & (pick < 0.012)] = np.inf
+    x[(pick > 0.012) & (pick < 0.014)] = -np.inf
+    x[(pick > 0.014) & (pick < 0.018)] += np.float32(9.0)           # beyond the table, often several per bucket
+    x[:, 5] = np.nan                                                # land
+    x[:, 6] = np.float32(0.25)                                      # ties: every anomaly 0
+    bt = binning.hobday_bins()
+    dcal = hot.upload_calendar(cal)
+    xd = torch.from_numpy(x).to(hot.device)
+
+    def same_tails(a, out):
+        ref = hot.tail_extract(out, dcal, bt)
+        hot.sync()
+        assert a["tails"]["list_rows"] == ref["list_rows"] == 32 and a["tails"]["max_bucket"] == ref["max_bucket"]
+        assert torch.equal(a["tails"]["aux"], ref["aux"]), "aux words differ from the extraction kernel's"
+        assert torch.equal(a["tails"]["tails"], ref["tails"]), "key lists differ from the extraction kernel's"
+
+    plain = hot.fixed_baseline(xd, dcal, None, None)
+    fused = hot.fixed_baseline(xd, dcal, None, None, tails_bins=bt)
+    hot.sync()
+    assert "tails" in fused and np.array_equal(fused["out"].cpu().numpy(), plain["out"].cpu().numpy(), equal_nan=True)
+    assert torch.equal(fused["invalid_count"], plain["invalid_count"]) and torch.equal(fused["mask"], plain["mask"])
+    same_tails(fused, fused["out"])
+    rp = (1955, 1958)                                               # reference period: the climatology of a few years only
+    fused_rp = hot.fixed_baseline(xd, dcal, rp, None, tails_bins=bt)
+    hot.sync()
+    same_tails(fused_rp, fused_rp["out"])
+    model, pmodel = calendar.detrend_model(calendar.decimal_year(tm), [1, 2], False)
+    xf = torch.nan_to_num(xd, nan=0.0, posinf=5.0, neginf=-5.0)     # the fit needs numbers; land stays land
+    xf[:, 5] = float("nan")
+    d0 = hot.detrend_fixed_baseline(xf, model, pmodel, True, dcal)
+    out0 = d0["out"].clone()
+    d1 = hot.detrend_fixed_baseline(xf, model, pmodel, True, dcal, tails_bins=bt)
+    hot.sync()
+    assert "tails" in d1 and np.array_equal(d1["out"].cpu().numpy(), out0.cpu().numpy(), equal_nan=True)
+    same_tails(d1, d1["out"])
+    with hot.ctx.options(FIXED_TAILS=0):                            # switched off: no lists, the extraction pass makes them later
+        assert "tails" not in hot.fixed_baseline(xd, dcal, None, None, tails_bins=bt)

@@ -95,3 +95,21 @@ def test_compute_without_gpu_fails_loudly(da):
         pytest.skip("GPU present")
     with pytest.raises(marex_amd.ProcessingError, match="needs a HIP device"):
         marex_amd.preprocess_data(da, window_year_baseline=2)
+
+
+def test_kernel_family_note_names_the_slower_paths_once(caplog):
+    """Options whose defaults encode performance cliffs: a call that leaves the tuned anomaly kernel says so at
+    INFO, once per distinct configuration."""
+    import logging
+
+    from marex_amd import engine
+
+    assert engine.shifting_kernel_family(15, 21, 1440, True) == "lean" and engine.shifting_kernel_family(5, 21, 8, False) == "lean"
+    assert engine.shifting_kernel_family(10, 21, 1440, True) == "fast" and engine.shifting_kernel_family(15, 21, 1441, True) == "fast"
+    assert engine.shifting_kernel_family(15, 15, 1440, True) == "fast" and engine.shifting_kernel_family(15, 31, 1440, True) == "general"
+    assert engine.shifting_kernel_family(9, 21, 1440, True) == "general"
+    engine._noted.discard("probe message")
+    with caplog.at_level(logging.INFO, logger="marex_amd"):
+        engine._note_path("probe message")
+        engine._note_path("probe message")
+    assert [r.getMessage() for r in caplog.records].count("probe message") == 1
