@@ -240,4 +240,18 @@ __device__ __forceinline__ float key_to_float(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
+// min / max of an int over the 64 lanes of the wave, in every lane (DPP inside the rows of 16, two cross-row shuffles): one LDS
+// atomic per WAVE instead of one per lane on a shared address (64 lanes on one address are 64 serial LDS operations)
+__device__ __forceinline__ int wave_min_i32(int m) {
+    int o;
+    o = __builtin_amdgcn_update_dpp(m, m, 0x128, 0xF, 0xF, false); m = o < m ? o : m;  // row_ror 8 / 4 / 2 / 1
+    o = __builtin_amdgcn_update_dpp(m, m, 0x124, 0xF, 0xF, false); m = o < m ? o : m;
+    o = __builtin_amdgcn_update_dpp(m, m, 0x122, 0xF, 0xF, false); m = o < m ? o : m;
+    o = __builtin_amdgcn_update_dpp(m, m, 0x121, 0xF, 0xF, false); m = o < m ? o : m;
+    o = __shfl_xor(m, 16, 64); m = o < m ? o : m;
+    o = __shfl_xor(m, 32, 64); m = o < m ? o : m;
+    return m;
+}
+__device__ __forceinline__ int wave_max_i32(int m) { return -wave_min_i32(-m); }
+
 #define MASK_DOY_CHUNKS 6  // default number of pieces the dayofyear axis is cut into by the doy-grouped streaming kernels

@@ -726,6 +726,7 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned* __restrict__ aux, i
                     s_iumax[dpar ^ 1] = -1;
                 }
             }
+            int iu_lo = 0x7fffffff, iu_hi = -1;  // this lane's contribution to the day's range of quantile bins
             if (!resolved) {
                 const int tot = pooled_tot();
                 if (tot > 0) {
@@ -751,13 +752,19 @@ k_thr_tails(const uint4* __restrict__ lists, const unsigned* __restrict__ aux, i
                     }
                     if (iu >= 0) {
                         emit_threshold(d, iu, ck, cb, qpos);
-                        atomicMin(&s_iumin[dpar], iu);
-                        atomicMax(&s_iumax[dpar], iu);
+                        iu_lo = iu_hi = iu;
                         resolved = true;
                     }
                 } else {
                     thr[(size_t)d * C + cell] = nan_f();  // empty window
                     resolved = true;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(iu_hi >= 0) != 0) {  // one pair of LDS atomics per wave, not one per lane on one address
+                const int wlo = wave_min_i32(iu_lo), whi = wave_max_i32(iu_hi);
+                if ((t & 63) == 0) {
+                    atomicMin(&s_iumin[dpar], wlo);
+                    atomicMax(&s_iumax[dpar], whi);
                 }
             }
 #ifdef MAREX_STAMPS
@@ -1099,9 +1106,14 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
     if (NPER > 6)
         return fail(ctx, -4, "marex_hobday_thresholds_tails_f32: %d rows per bucket in lists of %d: more than 6 lists", max_bucket, list_rows);
     const int tile_pref = ctx_opt(ctx, "THR_TILE", (ny > 0 && p > 0 && max_bucket >= 24) ? 32 : 16);
-    const bool big = (ny > 0 && p > 0) && tile_pref == 32 && (row1 - row0) >= 16 && nx >= 16;
-    const int NT = big ? 1024 : 256;
+    // 3216 (experiments): 32 wide x 16 tall tiles on 512 threads, P = 2 -- half a CU's LDS and registers per workgroup, so that
+    // workgroups of ANOTHER kernel (the anomaly kernel of the neighbouring stream) can share the CU; THR_LDS_PAD (KiB of unused
+    // dynamic LDS per workgroup) keeps a second tile of this kernel off the CU
+    const bool half = (ny > 0 && p == 2) && tile_pref == 3216 && (row1 - row0) >= 12 && nx >= 16;
+    const bool big = !half && (ny > 0 && p > 0) && tile_pref == 32 && (row1 - row0) >= 16 && nx >= 16;
+    const int NT = big ? 1024 : (half ? 512 : 256);
     int TR = (ny > 0 && p > 0) ? (big ? 32 : 16) : 1, TC = NT / TR;
+    const size_t lds_pad = (size_t)ctx_opt(ctx, "THR_LDS_PAD", 0) * 1024;
     bool tall = false;
     if (big && p == 2 && ctx_opt(ctx, "THR_TALL", 1)) {
         auto ntiles = [&](int tr, int tc) {
@@ -1116,7 +1128,7 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
     if (Dd < 1 || Dd > NDOY) {
         // every block pays a window build-up of wd buckets; pick the block length with the least total work per CU slot
         const long cus = device_cus(ctx), tiles = (long)tiles_x * tiles_y;
-        const long slots = cus * (big ? 1 : 4);
+        const long slots = cus * (big ? 1 : (half ? 2 : 4));
         long best = -1;
         for (int d = 16; d <= NDOY; ++d) {
             const long blocks = tiles * ((NDOY + d - 1) / d);
@@ -1134,16 +1146,18 @@ extern "C" int marex_hobday_thresholds_tails_f32(marex_ctx* ctx, const void* lis
 #define MAREX_TT_LAUNCH(PP, TCC, NTT, ...)                                                                                           \
     do {                                                                                                                             \
         if (NPER <= 1)                                                                                                               \
-            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 1, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
+            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 1, ##__VA_ARGS__>), grid, dim3(NTT), lds_pad, ctx->stream, MAREX_TT_ARGS); \
         else if (NPER <= 2)                                                                                                          \
-            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 2, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
+            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 2, ##__VA_ARGS__>), grid, dim3(NTT), lds_pad, ctx->stream, MAREX_TT_ARGS); \
         else /* two lists prefetched across the barrier, the others loaded at use */                                                 \
-            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 3, ##__VA_ARGS__>), grid, dim3(NTT), 0, ctx->stream, MAREX_TT_ARGS);       \
+            hipLaunchKernelGGL((k_thr_tails<PP, TCC, NTT, 3, ##__VA_ARGS__>), grid, dim3(NTT), lds_pad, ctx->stream, MAREX_TT_ARGS); \
     } while (0)
     {
         LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
         if (TR == 1)
             MAREX_TT_LAUNCH(0, 256, 256);
+        else if (half)
+            MAREX_TT_LAUNCH(2, 32, 512, 16);
         else if (big && p == 1)
             MAREX_TT_LAUNCH(1, 32, 1024);
         else if (big && p == 2 && tall)

@@ -243,6 +243,10 @@ k_thresholds(const unsigned short* __restrict__ bins, long T_out, long C, int ny
 #ifndef TB_BATCH
 #define TB_BATCH 16
 #endif
+#define TB_BWF 64     // bins of the band that follows the thresholds
+#define TB_MARGIN 6   // re-centre when the day's quantile bins come this close to a band edge
+#define TB_STEP 56    // band shift when answering stragglers (8 bins of overlap)
+static_assert(TB_STEP <= TB_BWF - 8, "straggler passes must overlap: a quantile bin between two tried bands would never be found");
 
 template <int P, int TC, int NT, int TR_ = NT / TC>
 __global__ void __launch_bounds__(NT, NT == 256 ? 4 : 1)
@@ -269,6 +273,8 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         gscratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)Dd * NT);
     __shared__ int s_gmin, s_gmax, s_unres;
     __shared__ unsigned tot_s[NT];  // per tile cell: number of samples in its window (top of the cumulative column)
+    __shared__ int s_lo[2], s_hi[2];        // per pass (parity): some output's quantile lies below / above the band
+    __shared__ int s_iumin[2], s_iumax[2];  // per day (parity): range of the quantile bins found
 
     const int t = threadIdx.x;
     // lane -> tile cell: rows are rotated by P so that the output rows P .. TR-P-1 fill the FIRST waves completely and
@@ -572,9 +578,8 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
 
     // One sweep over the first nd_pass days of the block.
     //   mode 0  coarse levels: group of the quantile bin for every output-day still marked 254
-    //   mode 1  fine levels, SPECULATIVE band (chosen from day 0): resolve what falls inside the band,
-    //           flag the rest (254) for the exact path
     //   mode 2  fine levels, exact band g_base..: resolve the output-days whose group lies in the band
+    //   (mode 1, the speculative fixed band of rounds 1-3, is gone: `follow` below walks the block with a band that moves)
     // init_pd < pd: day 0 of a coarse sweep sees only the 2*init_pd+1 central buckets -- good enough to PLACE the
     // speculative band (a wrong guess only sends the block to the exact path), never used for a result
     auto sweep = [&](int mode, int nd_pass, int ng, int init_pd, int d_off = 0) {  // d_off: first day of the sweep within the block
@@ -641,121 +646,6 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
                         thr[(size_t)d * C + cell] = nan_f();  // empty window
                     }
                 }
-            } else if (mode == 1 && ROWPOOL) {
-                const bool need = g != 255;
-                if (__builtin_amdgcn_ballot_w64(need) != 0) {  // wave-uniform: all 64 lanes run the shared part
-                    unsigned tv = 0;
-#pragma unroll
-                    for (int dr = -P; dr <= P; ++dr) tv += tot_s[cis + dr * TC];
-                    const int tot = (int)row_sum(tv);
-                    const double qpos = q * (double)tot;
-                    if (hint < 0 && g < 254) hint = ((g - g_base) << shift) + 1 + (gsz >> 1);
-                    const bool want = need && tot > 0;
-                    // the window find_level would start from, per lane; the row reads 12 levels from the smallest of them
-                    const int khi = BW + 1;
-                    int top = (khi - 1) & ~3;
-                    top = top > 60 ? 60 : (top < 0 ? 0 : top);
-                    int start = ((hint >= 0 ? hint : ((1 + khi) >> 1)) - TB_ROWBACK) & ~3;  // the 16-level row window starts further below yesterday's level than an 8-level one
-                    start = start < 0 ? 0 : (start > top ? top : start);
-                    constexpr int RW = TB_ROWWIN;  // levels the row reads at once (a multiple of 4)
-                    int u = row_min(want ? start : 0x7fffffff);
-                    u = u > 68 - RW ? 68 - RW : u;  // levels u .. u+RW-1 lie inside the 68-level column
-                    unsigned a[RW / 2];
-#pragma unroll
-                    for (int i = 0; i < RW / 2; ++i) a[i] = 0u;
-                    {
-                        const unsigned* base = &lev[cis * TB_LS] + (u >> 1);
-#pragma unroll
-                        for (int dr = -P; dr <= P; ++dr) {
-                            const uint2* p2 = reinterpret_cast<const uint2*>(base + dr * TC * TB_LS);
-#pragma unroll
-                            for (int i = 0; i < RW / 4; ++i) {
-                                const uint2 w = p2[i];
-                                a[2 * i] += w.x;
-                                a[2 * i + 1] += w.y;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < RW / 2; ++i) a[i] = row_sum(a[i]);
-                    int k = -1, ck = 0, cb = 0;
-                    bool solved = false;
-                    if (want) {
-                        const int qf = (int)floor(qpos);
-                        const int mm = (khi - u) < RW ? (khi - u) : RW;  // levels >= khi do not exist
-                        int Wv[RW];
-#pragma unroll
-                        for (int i = 0; i < RW; ++i) Wv[i] = (int)((a[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
-                        int n = 0;
-#pragma unroll
-                        for (int i = 0; i < RW; ++i) n += (i < mm) && (Wv[i] <= qf);
-                        if (n == 0) {  // the level at or below u: known only at the bottom
-                            if (u == 0) {
-                                k = 0;
-                                ck = Wv[0];
-                                solved = true;
-                            }
-                        } else if (n == mm) {  // nothing in the window exceeds qpos: the end of the levels, or look higher
-                            if (mm < RW) {
-                                k = khi;
-#pragma unroll
-                                for (int i = 0; i < RW; ++i)
-                                    if (i == mm - 1) cb = Wv[i];
-                                solved = true;
-                            }
-                        } else {
-                            k = u + n;
-#pragma unroll
-                            for (int i = 0; i < RW; ++i) {
-                                if (i == n - 1) cb = Wv[i];
-                                if (i == n) ck = Wv[i];
-                            }
-                            solved = true;
-                        }
-                        if (!solved && !(ablate & 32)) k = find_level(hint, 1, khi, qpos, true, ck, cb);  // rare: the lane's own windows
-                    }
-                    if (need) {
-                        if (tot > 0) {
-                            const bool ok = k >= 1 && k <= BW;
-                            if (ok) {
-                                hint = k;
-                                emit_threshold(d, B0 + k - 1, ck, cb, qpos);
-                                gst[dg][t] = 255;
-                            } else {
-                                hint = -1;
-                                gst[dg][t] = 254;
-                                s_unres = 1;
-                            }
-                        } else {
-                            gst[dg][t] = 255;
-                            thr[(size_t)d * C + cell] = nan_f();
-                        }
-                    }
-                }
-            } else if (mode == 1) {
-                if (g != 255) {
-                    const int tot = pooled_tot();
-                    if (tot > 0) {
-                        const double qpos = q * (double)tot;
-                        if (hint < 0 && g < 254) hint = ((g - g_base) << shift) + 1 + (gsz >> 1);
-                        int ck, cb;
-                        const int k = find_level(hint, 1, BW + 1, qpos, true, ck, cb);
-                        // inside the band iff cs[B0-1] <= qpos (k == 1 needs the check) and some band bin exceeds qpos
-                        const bool ok = k >= 1 && k <= BW;
-                        if (ok) {
-                            hint = k;
-                            emit_threshold(d, B0 + k - 1, ck, cb, qpos);
-                            gst[dg][t] = 255;
-                        } else {
-                            hint = -1;
-                            gst[dg][t] = 254;
-                            s_unres = 1;
-                        }
-                    } else {
-                        gst[dg][t] = 255;
-                        thr[(size_t)d * C + cell] = nan_f();
-                    }
-                }
             } else {
                 if (g < 254 && g >= g_base && g < g_base + ng) {
                     const int tot = pooled_tot();
@@ -784,6 +674,239 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         }
     };
 
+    // ---- the band FOLLOWS the thresholds (round 4; the logic of k_thr_tails on the bin matrix): one sweep over the block's days
+    // with one level per bin of a 64-bin band.  After every day the band is re-centred on the day's range of quantile bins
+    // whenever that range comes within TB_MARGIN bins of an edge (the columns are then rebuilt from the wd buckets of the next
+    // day: cheap, a bucket is a handful of samples per cell on this path), and an output whose quantile lies outside the band
+    // reports the direction: the tile rebuilds its columns around a band further down / up and answers the stragglers in extra
+    // passes of the same day.  Seasonal drift costs a rebuild every few weeks of the walk -- the speculative band of round 1
+    // sent the whole block through two or three more sweeps (the exact path) as soon as one output-day escaped.
+    auto follow = [&](int nd_pass, int b0_first) {
+        const int base_max = nb - TB_BWF > 0 ? nb - TB_BWF : 0;
+        auto clamp_b0 = [&](int b) { return b < 0 ? 0 : (b > base_max ? base_max : b); };
+        auto set_band = [&](int b0) {
+            B0 = clamp_b0(b0);
+            BW = nb - B0 < TB_BWF ? nb - B0 : TB_BWF;
+            nlev = BW + 2;
+            lsh = 0;
+            loff = 1 - B0;
+            lhi = BW + 1;
+        };
+        auto wrapd = [&](int d) { return ((d % NDOY) + NDOY) % NDOY; };
+        auto rebuild = [&](int d) {  // this lane's column of day d from scratch, current band (not yet prefix-summed)
+            for (int r = 0; r < TB_LS / 2; ++r) mycol2[r] = make_uint2(0u, 0u);
+            Pre cur = load_bucket(wrapd(d - pd));
+            for (int o = -pd + 1; o <= pd; ++o) {
+                const Pre nxt = load_bucket(wrapd(d + o));
+                apply_bucket(cur, +1);
+                cur = nxt;
+            }
+            apply_bucket(cur, +1);
+        };
+        set_band(b0_first);
+        if (t == 0) {
+            s_lo[0] = s_lo[1] = s_hi[0] = s_hi[1] = 0;
+            s_iumin[0] = s_iumin[1] = 0x7fffffff;
+            s_iumax[0] = s_iumax[1] = -1;
+        }
+        __syncthreads();
+        constexpr int nlp = (TB_BWF + 2 + 1) >> 1;
+        const int pass_limit = 2 * (nb / TB_STEP) + 9;
+        int hint = -1;
+        bool need_rebuild = true;
+        Pre pin, pout;
+        for (int dd = 0; dd < nd_pass; ++dd) {
+            const int d = d_begin + dd, dpar = dd & 1;
+            // ---------------- P1
+            if (need_rebuild) {
+                rebuild(d);
+                need_rebuild = false;
+                hint = -1;
+            } else {
+                unprefix(nlp);
+                apply_bucket(pin, +1);
+                apply_bucket(pout, -1);
+            }
+            tot_s[ci] = prefix(nlp);
+            if (dd + 1 < nd_pass) {
+                pin = load_bucket(wrapd(d + 1 + pd));
+                pout = load_bucket(wrapd(d - pd));
+            }
+            // ---------------- P2 (+ straggler passes)
+            bool resolved = !(is_out && !land);
+            int tried_lo = B0, tried_hi = B0;
+            bool excursion = false;
+            for (int pass = 0;; ++pass) {
+                const int par = pass & 1;
+                __syncthreads();
+                if (t == 0) {
+                    s_lo[par ^ 1] = 0;
+                    s_hi[par ^ 1] = 0;
+                    if (pass == 0) {
+                        s_iumin[dpar ^ 1] = 0x7fffffff;
+                        s_iumax[dpar ^ 1] = -1;
+                    }
+                }
+                const bool need = !resolved;
+                int k = -1, ck = 0, cb = 0, tot = 0;
+                double qpos = 0.0;
+                if constexpr (ROWPOOL) {
+                    if (__builtin_amdgcn_ballot_w64(need) != 0) {  // wave-uniform: all 64 lanes run the shared part
+                        unsigned tv = 0;
+#pragma unroll
+                        for (int dr = -P; dr <= P; ++dr) tv += tot_s[cis + dr * TC];
+                        tot = (int)row_sum(tv);
+                        qpos = q * (double)tot;
+                        const bool want = need && tot > 0;
+                        const int khi = BW + 1;
+                        int top = (khi - 1) & ~3;
+                        top = top > 60 ? 60 : (top < 0 ? 0 : top);
+                        int start = ((hint >= 0 ? hint : ((1 + khi) >> 1)) - TB_ROWBACK) & ~3;
+                        start = start < 0 ? 0 : (start > top ? top : start);
+                        constexpr int RW = TB_ROWWIN;
+                        int u = row_min(want ? start : 0x7fffffff);
+                        u = u > 68 - RW ? 68 - RW : u;
+                        unsigned a[RW / 2];
+#pragma unroll
+                        for (int i = 0; i < RW / 2; ++i) a[i] = 0u;
+                        {
+                            const unsigned* base = &lev[cis * TB_LS] + (u >> 1);
+#pragma unroll
+                            for (int dr = -P; dr <= P; ++dr) {
+                                const uint2* p2 = reinterpret_cast<const uint2*>(base + dr * TC * TB_LS);
+#pragma unroll
+                                for (int i = 0; i < RW / 4; ++i) {
+                                    const uint2 w = p2[i];
+                                    a[2 * i] += w.x;
+                                    a[2 * i + 1] += w.y;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < RW / 2; ++i) a[i] = row_sum(a[i]);
+                        if (want) {
+                            bool solved = false;
+                            const int qf = (int)floor(qpos);
+                            const int mm = (khi - u) < RW ? (khi - u) : RW;
+                            int Wv[RW];
+#pragma unroll
+                            for (int i = 0; i < RW; ++i) Wv[i] = (int)((a[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
+                            int n = 0;
+#pragma unroll
+                            for (int i = 0; i < RW; ++i) n += (i < mm) && (Wv[i] <= qf);
+                            if (n == 0) {
+                                if (u == 0) {
+                                    k = 0;
+                                    ck = Wv[0];
+                                    solved = true;
+                                }
+                            } else if (n == mm) {
+                                if (mm < RW) {
+                                    k = khi;
+#pragma unroll
+                                    for (int i = 0; i < RW; ++i)
+                                        if (i == mm - 1) cb = Wv[i];
+                                    solved = true;
+                                }
+                            } else {
+                                k = u + n;
+#pragma unroll
+                                for (int i = 0; i < RW; ++i) {
+                                    if (i == n - 1) cb = Wv[i];
+                                    if (i == n) ck = Wv[i];
+                                }
+                                solved = true;
+                            }
+                            if (!solved) k = find_level(hint, 1, khi, qpos, true, ck, cb);  // rare: the lane's own windows
+                        }
+                    }
+                } else {
+                    if (need) {
+                        tot = pooled_tot();
+                        if (tot > 0) {
+                            qpos = q * (double)tot;
+                            k = find_level(hint, 1, BW + 1, qpos, true, ck, cb);
+                        }
+                    }
+                }
+                int iu_lo = 0x7fffffff, iu_hi = -1;  // this lane's contribution to the day's range of quantile bins
+                if (need) {
+                    if (tot > 0) {
+                        int iu = -1;
+                        if (k >= 1 && k <= BW) {
+                            iu = B0 + k - 1;
+                            hint = k;
+                        } else if (k > BW && B0 + BW >= nb) {  // nothing exceeds qpos (q == 1): searchsorted gives nb, clipped to nb - 1
+                            iu = nb - 1;
+                            k = iu - B0 + 1;
+                            ck = pooled(k);
+                            cb = pooled(k - 1);
+                            hint = k;
+                        } else if (k > BW) {
+                            atomicOr(&s_hi[par], 1);
+                            hint = -1;
+                        } else {
+                            atomicOr(&s_lo[par], 1);
+                            hint = -1;
+                        }
+                        if (iu >= 0) {
+                            emit_threshold(d, iu, ck, cb, qpos);
+                            iu_lo = iu_hi = iu;
+                            resolved = true;
+                        }
+                    } else {
+                        thr[(size_t)d * C + cell] = nan_f();  // empty window
+                        resolved = true;
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(iu_hi >= 0) != 0) {  // one pair of LDS atomics per wave, not per lane
+                    const int wlo = wave_min_i32(iu_lo), whi = wave_max_i32(iu_hi);
+                    if ((t & 63) == 0) {
+                        atomicMin(&s_iumin[dpar], wlo);
+                        atomicMax(&s_iumax[dpar], whi);
+                    }
+                }
+                __syncthreads();
+                const int lo = s_lo[par], hi = s_hi[par];
+                if (!lo && !hi) break;
+                if (pass >= pass_limit) {  // cannot happen while the tried bands overlap (static_assert above); counted, never silent
+                    if (!resolved) {
+                        thr[(size_t)d * C + cell] = nan_f();
+                        atomicAdd(&stats->n_unresolved, 1u);
+                    }
+                    break;
+                }
+                // stragglers: a band further down (first) or further up than anything tried for this day
+                if (lo) {
+                    set_band(tried_lo - TB_STEP);
+                    tried_lo = B0;
+                } else {
+                    set_band(tried_hi + TB_STEP);
+                    tried_hi = B0;
+                }
+                excursion = true;
+                rebuild(d);
+                tot_s[ci] = prefix(nlp);  // same totals (band independent); columns are read after the barrier above
+                hint = -1;
+            }
+            // ---------------- band of the next day
+            if (dd + 1 < nd_pass) {
+                const int imin = s_iumin[dpar], imax = s_iumax[dpar];
+                if (imax >= 0) {
+                    const int span = imax - imin + 1;
+                    const bool near_edge = imin - B0 < TB_MARGIN || (B0 + BW - 1) - imax < TB_MARGIN;
+                    if (excursion || near_edge) {
+                        const int want = clamp_b0(span <= TB_BWF - 2 * TB_MARGIN ? imin - (TB_BWF - span) / 2 : imin - TB_MARGIN);
+                        if (want != B0) {
+                            set_band(want);
+                            need_rebuild = true;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
     __syncthreads();
     // placement: coarse quantile groups on the block's FIRST and LAST day -- thresholds drift with the season, and a band
     // placed on day 0 alone loses the days at the far end of a long block to the exact path (measured on a field whose p95
@@ -791,41 +914,17 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
     const int cpd = (coarse_pd >= 0 && coarse_pd < pd) ? coarse_pd : pd;
     sweep(0, 1, 0, cpd);
     const int gmin0 = s_gmin, gmax0 = s_gmax;
-    int gmin1 = gmin0, gmax1 = gmax0;
-    if (ndays > 1 && two_ended) {
-        __syncthreads();
-        if (t == 0) {
-            s_gmin = 255;
-            s_gmax = -1;
-        }
-        __syncthreads();
-        sweep(0, 1, 0, cpd, ndays - 1);
-        gmin1 = s_gmin;
-        gmax1 = s_gmax;
-    }
     __syncthreads();
-    const int nband = gpp < ngroups ? gpp : ngroups;
-    auto clamp_base = [&](int b) { return b < 0 ? 0 : (b + gpp > ngroups ? (ngroups - gpp > 0 ? ngroups - gpp : 0) : b); };
-    const bool seen0 = gmax0 >= 0, seen1 = gmax1 >= 0;
-    int gmin = seen0 && seen1 ? (gmin0 < gmin1 ? gmin0 : gmin1) : (seen0 ? gmin0 : gmin1);
-    int gmax = gmax0 > gmax1 ? gmax0 : gmax1;
-    if (!env_exact && gmax >= 0 && gmax - gmin + 1 <= gpp) {
-        // one speculative band of gpp groups around what the two ends need (room for drift on both sides)
-        const int spare = gpp - (gmax - gmin + 1);
-        g_base = clamp_base(gmin - (spare + 1) / 2);
-        sweep(1, ndays, nband, pd);
-    } else if (!env_exact && seen0 && seen1 && ndays >= 8 && gmax0 - gmin0 + 1 <= gpp && gmax1 - gmin1 + 1 <= gpp) {
-        // the drift across the block is wider than one band: one band per half, each anchored on its own end with all
-        // its spare groups on the side the thresholds come from / go to
-        const bool up = gmin1 + gmax1 > gmin0 + gmax0;
-        const int nd_a = ndays / 2;
-        g_base = clamp_base(up ? gmin0 : gmax0 - gpp + 1);
-        sweep(1, nd_a, nband, pd);
-        g_base = clamp_base(up ? gmax1 - gpp + 1 : gmin1);
-        sweep(1, ndays - nd_a, nband, pd, nd_a);
+    int gmin = gmin0, gmax = gmax0;
+    if (!env_exact && gmax0 >= 0) {
+        // first band: centred on the bins of the coarse groups day 0 needs (a bad start only costs passes, never a result)
+        const int blo = gmin0 << shift, bhi = ((gmax0 + 1) << shift) - 1;
+        const int span = bhi - blo + 1;
+        follow(ndays, span <= TB_BWF - 2 * TB_MARGIN ? blo - (TB_BWF - span) / 2 : blo - TB_MARGIN);
     } else if (t == 0) {
-        s_unres = 1;
+        s_unres = 1;  // THR_EXACT_PATH (tests), or a block whose first day has no window at all
     }
+    (void)two_ended;
     __syncthreads();
     if (s_unres && !(ablate & 8)) {  // exact path for whatever is not resolved yet
         for (int dd = 0; dd < ndays; ++dd)

@@ -284,10 +284,14 @@ class HotPath:
         return nd  # ws == 1: the per-cell threshold kernel (no tiles), any record length
 
     def fused_tails_ok(self, dcal: DeviceCalendar, bins: BinTable) -> bool:
-        """The fixed-baseline kernels (plain and behind the detrend fit) emit the key lists of their own output for buckets of at
-        most 128 rows and tables of at most 511 bins (option FIXED_TAILS=0: never -- the extraction pass then makes them)."""
+        """The fixed-baseline kernels (plain and behind the detrend fit) can emit the key lists of their own output for buckets
+        of at most 128 rows and tables of at most 511 bins.  Option FIXED_TAILS: 1 (default) = for buckets of at most 48 rows
+        -- the 48-row register kernel keeps four waves per SIMD with the sorting networks in it; the 128-row one drops to two and
+        measured SLOWER than kernel + extraction pass on the 100-yr field (27.9 vs 21.0 ms per band, profiles/r04_experiments.md)
+        --, 2 = whenever possible, 0 = never (the extraction pass makes the lists)."""
         nd = int(np.diff(dcal.plan.doy_start).max())
-        return bool(self.ctx_opt("FIXED_TAILS", 1)) and bool(self.ctx_opt("FIXED_REG", 1)) and 1 <= nd <= 128 and bins.nb <= 511
+        mode = self.ctx_opt("FIXED_TAILS", 1)
+        return bool(mode) and bool(self.ctx_opt("FIXED_REG", 1)) and 1 <= nd <= (128 if mode == 2 else 48) and bins.nb <= 511
 
     def _tail_buffers(self, nd: int, list_rows: int, Cn: int, wsp: Optional[dict]):
         nper = (nd + list_rows - 1) // list_rows

@@ -295,6 +295,17 @@ def test_fixed_baseline_kernels_emit_the_tails_of_their_own_output(hot, years, C
         assert torch.equal(a["tails"]["aux"], ref["aux"]), "aux words differ from the extraction kernel's"
         assert torch.equal(a["tails"]["tails"], ref["tails"]), "key lists differ from the extraction kernel's"
 
+    hot.ctx.set_option("FIXED_TAILS", 2)  # whenever possible (the default stops at 48-row buckets: the 128-row kernel is slower fused)
+    try:
+        _fixed_tails_case(hot, xd, dcal, bt, tm, same_tails)
+    finally:
+        hot.ctx.set_option("FIXED_TAILS", None)
+    with hot.ctx.options(FIXED_TAILS=0):                            # switched off: no lists, the extraction pass makes them later
+        assert "tails" not in hot.fixed_baseline(xd, dcal, None, None, tails_bins=bt)
+    assert ("tails" in hot.fixed_baseline(xd, dcal, None, None, tails_bins=bt)) == (years <= 48)   # the default
+
+
+def _fixed_tails_case(hot, xd, dcal, bt, tm, same_tails):
     plain = hot.fixed_baseline(xd, dcal, None, None)
     fused = hot.fixed_baseline(xd, dcal, None, None, tails_bins=bt)
     hot.sync()
@@ -314,5 +325,41 @@ def test_fixed_baseline_kernels_emit_the_tails_of_their_own_output(hot, years, C
     hot.sync()
     assert "tails" in d1 and np.array_equal(d1["out"].cpu().numpy(), out0.cpu().numpy(), equal_nan=True)
     same_tails(d1, d1["out"])
-    with hot.ctx.options(FIXED_TAILS=0):                            # switched off: no lists, the extraction pass makes them later
-        assert "tails" not in hot.fixed_baseline(xd, dcal, None, None, tails_bins=bt)
+
+
+@pytest.mark.parametrize("years,tile,dd", [(7, 16, 0), (7, 16, 9), (30, 16, 0), (30, 32, 0), (12, 32, 61)])
+def test_bin_matrix_band_kernel_follows_seasonal_and_patchy_thresholds(hot, years, tile, dd):
+    """k_thr_band (the bin-matrix path: short buckets with pooling, cfg2) with the band that FOLLOWS the thresholds (round 4):
+    a 95th percentile that swings by 2.4 K over the year and differs by 1.5 K between the two halves of the grid -- rebuilds as
+    the walk goes, straggler passes for cells the band cannot hold at once -- gives the oracle's bits; so do 5-sample buckets
+    (7 years), both tile sizes, short and long day blocks, q = 1 and a low quantile."""
+    tm, cal, _, rng = make_anomalies(years, 40 * 36, seed=50 + years)
+    doy = cal.doy_out.astype(np.float64)
+    amp = 0.5 + 0.45 * np.sin(2 * np.pi * (doy - 40) / 366.0)
+    field = rng.normal(0, 1, (cal.T_out, 40 * 36)).astype(np.float32) * amp[:, None].astype(np.float32)
+    field = field.reshape(-1, 40, 36)
+    field[:, :, 18:] *= np.float32(2.2)
+    field[:, 20:, :] += np.float32(0.3)
+    field[:, 3, 5] = np.nan                     # a land cell inside
+    anom = np.ascontiguousarray(field.reshape(cal.T_out, -1))
+    bt = binning.hobday_bins()
+    dcal = hot.upload_calendar(cal)
+    ad = torch.from_numpy(anom).to(hot.device)
+    binsb = hot.digitize(ad, dcal, bt)
+    opts = {"THR_TILE": tile}
+    if dd:
+        opts["THR_DD"] = dd
+    for pct, wd, ws in ((95.0, 11, 5), (100.0, 5, 3), (60.0, 11, 5)):
+        with hot.ctx.options(**opts):
+            t = hot.hobday_thresholds(binsb, ad, dcal, bt, pct / 100.0, wd, ws, 40, 36)
+            hot.sync()
+        exp_thr, exp_stats = orc.hobday_thresholds_approx(anom, cal.doy_out, pct / 100.0, wd, ws, bt.edges, bt.centres, 40, 36)
+        assert np.array_equal(t["thr_doy_major"].cpu().numpy().T, exp_thr, equal_nan=True), (pct, wd, ws)
+        st = HotPath.decode_thr_stats(t["stats_dev"])
+        assert st["n_too_low"] == exp_stats["n_too_low"] and st["n_too_high"] == exp_stats["n_too_high"]
+    with hot.ctx.options(THR_EXACT_PATH=1, **opts):  # the exact path (coarse + fine sweeps) is still there: same bits
+        t = hot.hobday_thresholds(binsb, ad, dcal, bt, 0.95, 11, 5, 40, 36, rows=(3, 31))
+        hot.sync()
+    exp_thr, _ = orc.hobday_thresholds_approx(anom, cal.doy_out, 0.95, 11, 5, bt.edges, bt.centres, 40, 36)
+    sl = slice(3 * 36, 31 * 36)
+    assert np.array_equal(t["thr_doy_major"].cpu().numpy().T[sl], exp_thr[sl], equal_nan=True)
