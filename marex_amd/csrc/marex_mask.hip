@@ -318,25 +318,6 @@ __global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ in,
     }
 }
 
-// The threshold layout change itself ([366, C] -> [C, 366]): a workgroup takes 32 cells and ALL rows, so what it writes is ONE
-// contiguous run of 32 x rows floats (rows of 366 floats are 1464 bytes: a 32 x 32 tile writes 128-byte pieces at offsets that
-// are multiples of 8 bytes only, every piece two partial lines -- measured 2.5 TB/s on the 10-yr field, 1.2 ms of its 28).
-template <int ROWS>
-__global__ void __launch_bounds__(256) k_transpose_rows(const float* __restrict__ in, long cols, float* __restrict__ out) {
-    __shared__ float tile[ROWS * 33];
-    const long c0 = (long)blockIdx.x * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 cells x 8 rows per step
-    const bool ok = c0 + tx < cols;
-    for (int r = ty; r < ROWS; r += 8) tile[r * 33 + tx] = ok ? in[(size_t)r * cols + c0 + tx] : 0.f;
-    __syncthreads();
-    const long n = (cols - c0 < 32 ? cols - c0 : 32) * ROWS;  // floats of this workgroup's run
-    float* o = out + (size_t)c0 * ROWS;
-    for (long i = threadIdx.x; i < n; i += 256) {
-        const int c = (int)(i / ROWS), r = (int)(i - (long)c * ROWS);
-        o[i] = tile[r * 33 + c];
-    }
-}
-
 // Verdict of the validation (detect.py:205-279) from the per-cell results of the anomaly kernels: over cells c0 .. c1-1
 // out[0] = ocean cells (mask != 0), out[1] = non-finite values in ocean cells, out[2] = ocean cells with any,
 // out[3] = the largest count in one ocean cell.
@@ -392,10 +373,7 @@ extern "C" int marex_transpose_f32(marex_ctx* ctx, const float* in, int64_t rows
     dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
     {
         LaunchTimer lt(ctx, MAREX_K_TRANSPOSE);
-        if (rows == NDOY && ctx_opt(ctx, "TRANSPOSE_ROWS", 1))
-            hipLaunchKernelGGL(k_transpose_rows<NDOY>, dim3(grid.x), dim3(256), 0, ctx->stream, in, (long)cols, out);
-        else
-            hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, ctx->stream, in, (long)rows, (long)cols, out);
+        hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, ctx->stream, in, (long)rows, (long)cols, out);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;

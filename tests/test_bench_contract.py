@@ -22,12 +22,22 @@ def _bench_module():
     return mod
 
 
-def test_headline_line_has_the_contract_keys_and_consistent_numbers():
-    d = _line("r03_cfg3_bench.json")
+def _rounds():
+    import glob
+    import re
+
+    return sorted({re.search(r"(r\d\d)_cfg3_bench", f).group(1) for f in glob.glob(os.path.join(ROOT, "profiles", "r??_cfg3_bench.json"))
+                   if re.search(r"(r\d\d)_cfg3_bench", f).group(1) >= "r03"})
+
+
+@pytest.mark.parametrize("rnd", _rounds())
+def test_headline_line_has_the_contract_keys_and_consistent_numbers(rnd):
+    d = _line(f"{rnd}_cfg3_bench.json")
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
+    assert "failed" not in d
     assert d["unit"].replace("*", "·") in base["metric"].replace("*", "·") or "Mcells" in d["unit"]
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
@@ -39,19 +49,43 @@ def test_headline_line_has_the_contract_keys_and_consistent_numbers():
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
     assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-6)
     assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]
+    pr = d["pipeline_roofline"]  # the north-star fraction: whole-path bytes / step time
+    assert pr["achieved"] == pytest.approx(pr["algorithmic_bytes_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3) / 1e9, rel=1e-6)
+    assert pr["frac"] == pytest.approx(pr["achieved"] / pr["peak"], rel=1e-9) and pr["frac"] < r["frac"]
+    if rnd >= "r04":  # listed before the single-kernel figure, so that nobody reads the latter as "the target is met"
+        keys = list(d)
+        assert keys.index("pipeline_roofline") < keys.index("roofline")
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     s = d["config"]["summary"]
-    assert s["n_ocean"] == 757773 and s["n_extreme"] == 1191420079  # the same field, the same answer, whatever the tiling
-    assert d["extra"]["single_stream"]["n_extreme"] == s["n_extreme"]
+    assert d["extra"]["single_stream"]["n_extreme"] == s["n_extreme"]  # the same field, the same answer, whatever the schedule
+    assert s.get("thr_unresolved", 0) == 0 and s["invalid_total"] == 0
 
 
-@pytest.mark.parametrize("name", ["r03_cfg2_bench.json", "r03_cfg4_bench.json", "r03_cfg5_bench.json", "r03_cfg3_single_stream_bench.json"])
+def test_every_kept_line_of_the_100yr_field_gives_the_same_counts():
+    """Tilings (6 bands x 2 streams, single stream, two ranks on one card), rounds and kernel generations: the field is the same
+    synthetic field, so every committed cfg3 line must report the same ocean cells and the same number of extremes (derived by
+    comparing the lines with each other, not pinned to a literal)."""
+    import glob
+
+    lines = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_cfg3*bench*.json"))):
+        d = _line(os.path.basename(f))
+        if "summary" in d.get("config", {}):
+            lines.append((os.path.basename(f), d["config"]["summary"]["n_ocean"], d["config"]["summary"]["n_extreme"], d["n_gpus"]))
+    assert len(lines) >= 2
+    assert len({(a, b) for _, a, b, _ in lines}) == 1, lines
+
+
+@pytest.mark.parametrize("name", [n for r in _rounds() for n in (f"{r}_cfg2_bench.json", f"{r}_cfg4_bench.json", f"{r}_cfg5_bench.json",
+                                                                  f"{r}_cfg3_single_stream_bench.json")])
 def test_other_lines_parse_and_price_their_dominant_kernel(name):
+    if not os.path.exists(os.path.join(ROOT, "profiles", name)):
+        pytest.skip(f"{name} not kept this round")
     d = _line(name)
     r = d["roofline"]
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9) and 0 < r["frac"] < 1
-    assert d["ms_per_step"] > 0 and d["value"] > 0 and "workload" in d["config"]
+    assert d["ms_per_step"] > 0 and d["value"] > 0 and "workload" in d["config"] and "failed" not in d
 
 
 def test_band_count_tiles_the_field_in_whole_tile_rows():

@@ -280,10 +280,8 @@ def test_lean_and_fast_anomaly_kernels_agree_on_the_bin_matrix(hot, W, years, st
 
 @pytest.mark.parametrize("rows,cols", [(366, 1), (366, 33), (366, 1000), (366, 4096), (12, 77)])
 def test_threshold_transpose(hot, rows, cols):
-    """[366, C] -> [C, 366] (one contiguous run of 32 cells per workgroup) and the generic tiles for any other shape."""
+    """[366, C] -> [C, 366] and any other shape (32 x 32 tiles through LDS)."""
     a = torch.arange(rows * cols, dtype=torch.float32, device=hot.device).reshape(rows, cols) * 0.5
-    for opt in (1, 0):
-        with hot.ctx.options(TRANSPOSE_ROWS=opt):
-            t = hot.transpose(a)
-            hot.sync()
-        assert t.shape == (cols, rows) and torch.equal(t, a.T.contiguous())
+    t = hot.transpose(a)
+    hot.sync()
+    assert t.shape == (cols, rows) and torch.equal(t, a.T.contiguous())
