@@ -631,6 +631,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
             // ---------------- P2: quantile level of this lane's output cell
             const int g = (ablate & 1) ? 255 : gst[dg][t];
             if (mode == 0) {
+                int g_lo = 255, g_hi = -1;
                 if (g == 254) {
                     const int tot = pooled_tot();
                     if (tot > 0) {
@@ -639,11 +640,17 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
                         if (gg >= nlev) gg = nlev - 1;  // nothing above qpos: iu clips to nb-1
                         hint = gg;
                         gst[dg][t] = (unsigned char)gg;
-                        atomicMin(&s_gmin, gg);
-                        atomicMax(&s_gmax, gg);
+                        g_lo = g_hi = gg;
                     } else if (init_pd == pd) {
                         gst[dg][t] = 255;
                         thr[(size_t)d * C + cell] = nan_f();  // empty window
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(g_hi >= 0) != 0) {  // one pair of LDS atomics per wave (64 lanes on one address are 64 serial operations)
+                    const int wlo = wave_min_i32(g_lo), whi = wave_max_i32(g_hi);
+                    if ((t & 63) == 0) {
+                        atomicMin(&s_gmin, wlo);
+                        atomicMax(&s_gmax, whi);
                     }
                 }
             } else {
