@@ -326,9 +326,13 @@ __device__ __forceinline__ void tl_bump_chunk(const uint4& ch, int n, int B0, in
 #undef MAREX_BUMP_HI
 
 #define TT_LS 34       // dwords per lane column (68 uint16 levels; stride 34 keeps 8-byte alignment, conflict-free b64)
-#define TT_BW 64       // bins per band
+#ifndef TT_BW
+#define TT_BW 64       // bins per band (experiments: -DTT_BW=48 -DTT_STEP=40; must stay <= 64: the column has 68 levels)
+#endif
 #define TT_MARGIN 6    // re-centre when the day's quantile bins come this close to a band edge
+#ifndef TT_STEP
 #define TT_STEP 56     // band shift when answering stragglers (8 bins of overlap)
+#endif
 static_assert(TT_STEP <= TT_BW - 8, "straggler passes must overlap: a quantile bin between two tried bands would never be found");
 #define TT_NPF 2       // chunk-0s of a bucket prefetched across the barrier (the other lists are loaded at use)
 

@@ -254,7 +254,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
            int Dd, int shift, int env_exact, int ablate, const int* __restrict__ doy_start,
            const float* __restrict__ first_anom, const float* __restrict__ centres, int nb, double q, int wd,
            float lower_bound, float upper_bound, float* __restrict__ thr, marex_thr_stats* __restrict__ stats,
-           unsigned char* __restrict__ gscratch, int coarse_pd, int two_ended) {
+           unsigned char* __restrict__ gscratch, int coarse_pd, int two_ended, int bwf) {
     // TR x TC tile cells on NT threads; a tile whose cell count is not a multiple of 64 (34 x 30 = 1020) leaves the last
     // lanes of the last wave without a cell: they own a private, unused column and take part in the barriers only
     constexpr int TR = TR_;
@@ -689,11 +689,12 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
     // passes of the same day.  Seasonal drift costs a rebuild every few weeks of the walk -- the speculative band of round 1
     // sent the whole block through two or three more sweeps (the exact path) as soon as one output-day escaped.
     auto follow = [&](int nd_pass, int b0_first) {
-        const int base_max = nb - TB_BWF > 0 ? nb - TB_BWF : 0;
+        const int step = bwf - 8;  // straggler bands overlap by 8 bins
+        const int base_max = nb - bwf > 0 ? nb - bwf : 0;
         auto clamp_b0 = [&](int b) { return b < 0 ? 0 : (b > base_max ? base_max : b); };
         auto set_band = [&](int b0) {
             B0 = clamp_b0(b0);
-            BW = nb - B0 < TB_BWF ? nb - B0 : TB_BWF;
+            BW = nb - B0 < bwf ? nb - B0 : bwf;
             nlev = BW + 2;
             lsh = 0;
             loff = 1 - B0;
@@ -717,8 +718,8 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
             s_iumax[0] = s_iumax[1] = -1;
         }
         __syncthreads();
-        constexpr int nlp = (TB_BWF + 2 + 1) >> 1;
-        const int pass_limit = 2 * (nb / TB_STEP) + 9;
+        const int nlp = (bwf + 2 + 1) >> 1;
+        const int pass_limit = 2 * (nb / step) + 9;
         int hint = -1;
         bool need_rebuild = true;
         Pre pin, pout;
@@ -885,10 +886,10 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
                 }
                 // stragglers: a band further down (first) or further up than anything tried for this day
                 if (lo) {
-                    set_band(tried_lo - TB_STEP);
+                    set_band(tried_lo - step);
                     tried_lo = B0;
                 } else {
-                    set_band(tried_hi + TB_STEP);
+                    set_band(tried_hi + step);
                     tried_hi = B0;
                 }
                 excursion = true;
@@ -903,7 +904,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
                     const int span = imax - imin + 1;
                     const bool near_edge = imin - B0 < TB_MARGIN || (B0 + BW - 1) - imax < TB_MARGIN;
                     if (excursion || near_edge) {
-                        const int want = clamp_b0(span <= TB_BWF - 2 * TB_MARGIN ? imin - (TB_BWF - span) / 2 : imin - TB_MARGIN);
+                        const int want = clamp_b0(span <= bwf - 2 * TB_MARGIN ? imin - (bwf - span) / 2 : imin - TB_MARGIN);
                         if (want != B0) {
                             set_band(want);
                             need_rebuild = true;
@@ -927,7 +928,7 @@ k_thr_band(const unsigned short* __restrict__ bins, long T_out, long C, int ny, 
         // first band: centred on the bins of the coarse groups day 0 needs (a bad start only costs passes, never a result)
         const int blo = gmin0 << shift, bhi = ((gmax0 + 1) << shift) - 1;
         const int span = bhi - blo + 1;
-        follow(ndays, span <= TB_BWF - 2 * TB_MARGIN ? blo - (TB_BWF - span) / 2 : blo - TB_MARGIN);
+        follow(ndays, span <= bwf - 2 * TB_MARGIN ? blo - (bwf - span) / 2 : blo - TB_MARGIN);
     } else if (t == 0) {
         s_unres = 1;  // THR_EXACT_PATH (tests), or a block whose first day has no window at all
     }
@@ -1052,7 +1053,9 @@ extern "C" int marex_hobday_thresholds_f32(marex_ctx* ctx, const uint16_t* bins,
             gscratch = ctx->thr_scratch;
         }
         const int coarse_pd = ctx_opt(ctx, "THR_COARSE_PD", 1);
-#define MAREX_BAND_ARGS bins, (long)T_out, (long)C, ny, nx, row0, row1, tiles_x, Dd, shift, ctx_opt(ctx, "THR_EXACT_PATH", 0), MAREX_ABLATE_OPT(ctx, "THR_ABLATE"), doy_start, first_anom, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats, gscratch, coarse_pd, ctx_opt(ctx, "THR_TWO_ENDS", 1)
+        int bwf = ctx_opt(ctx, "THR_BWF", TB_BWF);  // bins of the band that follows the thresholds (experiments: 24..64)
+        bwf = bwf < 24 ? 24 : (bwf > TB_BWF ? TB_BWF : bwf);
+#define MAREX_BAND_ARGS bins, (long)T_out, (long)C, ny, nx, row0, row1, tiles_x, Dd, shift, ctx_opt(ctx, "THR_EXACT_PATH", 0), MAREX_ABLATE_OPT(ctx, "THR_ABLATE"), doy_start, first_anom, centres, nb, q, wd, lower_bound, upper_bound, thr_doy_major, stats, gscratch, coarse_pd, ctx_opt(ctx, "THR_TWO_ENDS", 1), bwf
         {
             LaunchTimer lt(ctx, MAREX_K_THRESHOLDS);
             if (TR == 1)
