@@ -670,11 +670,18 @@ def preprocess_data(
     quiet: Optional[bool] = None,
     device: int = 0,
     devices: Optional[List[int]] = None,
+    require_dask: bool = False,
     _validation: str = "raise",
     _own_rows: Optional[Tuple[int, int]] = None,
     _defer_warnings: bool = False,
 ):
     """Anomalies, thresholds and the boolean extreme mask of a (time, [lat,] lon / cells) field.
+
+    ``require_dask=True`` (extension; default False): refuse an input that is not Dask-backed with the reference's own
+    ``DataValidationError`` ("Input DataArray must be Dask-backed", detect.py:558-568).  The eager call takes in-memory and
+    device-resident arrays on purpose (documented deviation); a caller that wants the reference's contract to the letter --
+    or that must not materialise a larger-than-memory field by accident -- switches it on, or uses
+    :func:`marex_amd.dask_adapter.preprocess_data_lazy`, which always insists.
 
     ``_validation="return"`` (internal: :mod:`marex_amd.dask_adapter` runs one spatial block of a larger field per call): the
     verdict of ``_validate_data_values`` is not raised but returned as ``ds.attrs["_validation"]`` -- a block may be all land,
@@ -718,6 +725,16 @@ def preprocess_data(
     logger.info(f"Starting data preprocessing - Method: {method_anomaly} -> {method_extreme}")
 
     dimensions, coordinates = _infer_dims_coords(da, dimensions, coordinates)
+    if require_dask:  # detect.py:558-568, same place in the sequence of checks (after the dims / coords inference)
+        data = getattr(da, "data", None)
+        if not (hasattr(data, "__dask_graph__") or hasattr(data, "dask")):
+            raise create_data_validation_error(
+                "Input DataArray must be Dask-backed",
+                details="Preprocessing requires chunked data for efficient computation",
+                suggestions=["Convert to Dask array: da = da.chunk({'time': 30})",
+                             "Load with chunking: xr.open_dataset('file.nc', chunks={'time': 30})"],
+                data_info={"data_type": type(data).__name__, "shape": tuple(da.shape)},
+            )
     _check_reference_period_allowed(reference_period, method_anomaly)
     if method_anomaly not in _ANOMALY_METHODS:
         raise ConfigurationError(

@@ -113,3 +113,13 @@ def test_kernel_family_note_names_the_slower_paths_once(caplog):
         engine._note_path("probe message")
         engine._note_path("probe message")
     assert [r.getMessage() for r in caplog.records].count("probe message") == 1
+
+
+def test_require_dask_is_the_references_error(da):
+    """detect.py:558-568 on request: the eager call accepts in-memory arrays (documented deviation), `require_dask=True` refuses
+    them with the reference's message -- after the dims / coords inference, before anything touches the device."""
+    with pytest.raises(DataValidationError, match=r"Input DataArray must be Dask-backed") as ei:
+        marex_amd.preprocess_data(da, require_dask=True)
+    assert "chunk({'time': 30})" in str(ei.value) or any("chunk" in s for s in getattr(ei.value, "suggestions", []))
+    with pytest.raises(DataValidationError, match=r"Missing required dimensions"):  # the order of the reference's checks
+        marex_amd.preprocess_data(da, dimensions={"time": "time", "x": "longitude", "y": "lat"}, require_dask=True)
